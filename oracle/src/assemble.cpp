@@ -1,0 +1,279 @@
+// TEST INFRASTRUCTURE ONLY -- oracle restatement of `platanus_b assemble` (assemble.cpp:116-782),
+// single-thread schedule.  Stage order and every floating-point expression follow the reference
+// literally: they decide the k schedule, the cutoffs and the coverage roundings.
+#include "assemble.hpp"
+#include "graph.hpp"
+#include <cfloat>
+#include <climits>
+#include <cmath>
+#include <cstdlib>
+#include <iostream>
+#include <sstream>
+#include <tuple>
+
+namespace pbo {
+
+// assemble.cpp:700-715
+double calc_log_probability_join(u64 coverage_cutoff, double avg_cov, double avg_len, u64 large_k, u64 small_k)
+{
+    double p, s = 0;
+    const double c = avg_cov * (avg_len - large_k + 1.0) / avg_len;
+    for (u64 i = 0; i < coverage_cutoff; ++i) {
+        p = 0;
+        for (u64 j = 1; j <= i; ++j) p += log(c) - log(static_cast<double>(j));
+        s += exp(p);
+    }
+    s = exp(-c + log(s));
+    return ((large_k - small_k) + 1.0) * (-s);
+}
+
+// assemble.cpp:723-736
+u64 decrease_coverage_cutoff(u64 coverage_cutoff, double avg_cov, double avg_len, double min_log_p_join, u64 large_k, u64 small_k)
+{
+    if (coverage_cutoff <= 1) return 1;
+    u64 i;
+    for (i = coverage_cutoff; i > 1; --i)
+        if (calc_log_probability_join(i, avg_cov, avg_len, large_k, small_k) > min_log_p_join) break;
+    return i;
+}
+
+// assemble.cpp:657-694
+u64 extend_kmer(double min_log_p_join, double avg_cov, double avg_len, u64 min_cov, double max_k_ratio,
+                std::vector<unsigned> &k, std::vector<u64> &cutoff, u64 step, bool verbose)
+{
+    u64 i, j;
+    const u64 min_max_k = static_cast<long>(avg_len * max_k_ratio + 0.5);
+    if (verbose) {
+        std::cerr << "\nKMER_EXTENSION:" << std::endl;
+        std::cerr << "K=" << k[0] << ", KMER_COVERAGE=" << avg_cov * (avg_len - k[0] + 1.0) / avg_len;
+        std::cerr << " (>= " << cutoff[0] << "), COVERAGE_CUTOFF=" << cutoff[0] << std::endl;
+    }
+    for (i = 1; k[i - 1] <= avg_len; ++i) {
+        k.push_back(0);
+        cutoff.push_back(0);
+        for (j = 1; j <= step + 1; ++j) {
+            k[i] = k[i - 1] + j;
+            cutoff[i] = decrease_coverage_cutoff(cutoff[i - 1], avg_cov, avg_len, min_log_p_join, k[i], k[i - 1]);
+            if (cutoff[i] < min_cov) cutoff[i] = min_cov;
+            if (k[i - 1] + j > min_max_k && calc_log_probability_join(cutoff[i], avg_cov, avg_len, k[i], k[i - 1]) < min_log_p_join)
+                break;
+        }
+        --(k[i]);
+        cutoff[i] = decrease_coverage_cutoff(cutoff[i - 1], avg_cov, avg_len, min_log_p_join, k[i], k[i - 1]);
+        if (cutoff[i] < min_cov) cutoff[i] = min_cov;
+        if (k[i] == k[i - 1]) break;
+        if (verbose) {
+            std::cerr << "K=" << k[i] << ", KMER_COVERAGE=" << avg_cov * (avg_len - k[i] + 1.0) / avg_len;
+            std::cerr << ", COVERAGE_CUTOFF=" << cutoff[i] << ", PROB_SPLIT=10e"
+                      << log10(1.0 - exp(calc_log_probability_join(cutoff[i], avg_cov, avg_len, k[i], k[i - 1]))) << std::endl;
+        }
+    }
+    return i;
+}
+
+namespace {
+
+struct Run {
+    const AssembleOptions &opt;
+    ReadSet all_reads;            // allReadFP
+    ReadSet reads;                // readFP (cumulatively filtered, assemble.cpp:164-171, counter.h:908-909)
+    u64 memory;
+    double min_log_p_join;
+    double avg_len = 0, avg_cov = 0;
+    std::vector<unsigned> k;
+    std::vector<u64> cutoff;
+    u64 num_k = 0;
+    u64 dh_size = 0;
+    // one counter and one graph object per key width, reused across rounds (assemble.h:55-60)
+    std::tuple<Counter<1>, Counter<2>, Counter<3>, Counter<4>, Counter<5>> counters;
+    std::tuple<Graph<1>, Graph<2>, Graph<3>, Graph<4>, Graph<5>> graphs;
+    std::vector<ContigRecord> contigs, junctions;   // contigFP / junctionFP
+
+    explicit Run(const AssembleOptions &o) : opt(o) {}
+    template <int W> Counter<W> &counter() { return std::get<W - 1>(counters); }
+    template <int W> Graph<W> &graph() { return std::get<W - 1>(graphs); }
+
+    // assemble.cpp:304-386
+    template <int W> void initial(double cutoff_factor)
+    {
+        Counter<W> &c = counter<W>();
+        Graph<W> &g = graph<W>();
+        if (opt.verbose) std::cerr << "K = " << k[0] << ", saving kmers from reads..." << std::endl;
+        g.set_k(k[0]);
+        cutoff.clear();
+        dh_size = c.count_reads(k[0], reads, memory);
+        if (!opt.repeat)
+            cutoff.push_back(opt.n_cutoff != 0 ? opt.n_cutoff : std::max<u64>(c.left_local_minimal_value(1) / 2, 2ull));
+        else
+            cutoff.push_back(opt.n_cutoff != 0 ? opt.n_cutoff : std::max<u64>(c.left_local_minimal_value(1), 2ull));
+        avg_cov = c.occ_average(cutoff[0], c.max_occ);
+        if (avg_cov * cutoff_factor > cutoff.back()) cutoff.back() = avg_cov * cutoff_factor;
+        avg_cov = c.occ_average(cutoff[0], c.max_occ);
+        if (opt.expected_cov != "") avg_cov = atof(opt.expected_cov.c_str());
+        avg_len = c.length_average(0, MAX_READ_LEN);
+        avg_cov = avg_cov * avg_len / (avg_len - k[0] + 1.0);
+        if (opt.verbose) std::cerr << "AVE_READ_LEN=" << avg_len << std::endl;
+        num_k = extend_kmer(min_log_p_join, avg_cov, avg_len, opt.min_cov, opt.max_k_ratio, k, cutoff, opt.step, opt.verbose);
+
+        std::ostringstream oss;
+        oss << opt.out_prefix << '_' << k[0] << "merFrq.tsv";
+        c.write_occ_distribution(oss.str());
+
+        std::vector<Key<W>> sorted = c.sorted_keys(cutoff[0]);
+        dh_size = c.load_kmers(cutoff[0], dh_size);
+        if (opt.kmer_occ_only) {
+            c.write_table_binary(opt.out_prefix + "_kmer_occ.bin");
+            return;
+        }
+        g.make_initial(c.table, sorted);
+        c.table.release();
+        g.cut_branch_iterative(opt.verbose);
+        if (opt.expected_cov == "") avg_cov = g.average_coverage_excluding_bubble();
+        else avg_cov = atof(opt.expected_cov.c_str());
+        if (opt.repeat) {
+            g.delete_erroneous_iterative(ULONG_MAX, 1.75 * avg_cov + 0.5, opt.verbose);
+            g.crush_bubble_iterative(DBL_MAX, opt.verbose);
+        }
+        avg_cov = avg_cov * avg_len / (avg_len - k[0] + 1.0);
+    }
+
+    // assemble.cpp:449-459 saveGraph
+    template <int W> void save_graph(unsigned next_k, ReadSet &rfp)
+    {
+        Counter<W> &c = counter<W>();
+        c.table.resize(dh_size);
+        graph<W>().save_edge_kmers(c.table, next_k);
+        if (opt.verbose) std::cerr << "extracting reads (containing kmer used in contig assemble)..." << std::endl;
+        rfp = c.pickup_reads_matching_table(rfp);
+        c.table.release();
+    }
+
+    // assemble.cpp:762-782
+    template <int WP, int WN> void update_dh_size()
+    {
+        const u64 estimate = graph<WP>().estimate_kmers_on_straight();
+        const u64 size = table_size_for_keys(estimate);
+        dh_size = std::max(size, table_size_for_memory(memory, WN));
+    }
+
+    // assemble.cpp:467-498
+    template <int W> void redo(unsigned kk, u64 position)
+    {
+        Counter<W> &c = counter<W>();
+        Graph<W> &g = graph<W>();
+        if (opt.verbose) std::cerr << "K = " << kk << ", saving additional kmers(not found in contigs) from reads..." << std::endl;
+        c.count_reads_considering_table(kk, reads);
+        if (opt.verbose) std::cerr << "COVERAGE_CUTOFF = " << cutoff[position] << std::endl;
+        std::vector<Key<W>> sorted = c.sorted_keys(cutoff[position]);
+        dh_size = c.load_kmers(cutoff[position], dh_size);
+        g.set_k(kk);
+        g.make_initial(c.table, sorted);
+        c.table.release();
+        g.cut_branch_iterative(opt.verbose);
+        const unsigned kmer_cov = avg_cov * (avg_len - kk + 1.0) / avg_len + 0.5;
+        if (opt.repeat) {
+            g.delete_erroneous_iterative(ULONG_MAX, 1.75 * kmer_cov + 0.5, opt.verbose);
+            g.crush_bubble_iterative(DBL_MAX, opt.verbose);
+        }
+    }
+
+    // assemble.cpp:392-443
+    template <int WP, int WN> void save_and_redo(unsigned kk, unsigned prev_k, u64 position)
+    {
+        save_graph<WP>(kk, reads);
+        update_dh_size<WP, WN>();
+        DHash<WN> tmp;
+        tmp.resize(dh_size);
+        graph<WP>().template save_contig<WN>(kk, (avg_len - kk + 1.0) / (avg_len - prev_k + 1.0), tmp);
+        graph<WP>().delete_all();
+        if (opt.verbose) std::cerr << "K = " << kk << ", loading kmers from contigs..." << std::endl;
+        counter<WN>().table = std::move(tmp);
+        redo<WN>(kk, position);
+    }
+
+    // assemble.cpp:506-622
+    template <int W> void output_and_after(unsigned kk)
+    {
+        Counter<W> &c = counter<W>();
+        Graph<W> &g = graph<W>();
+        const u64 left_min = g.left_minimal_coverage();
+        const u64 length_cutoff = kk * 2;
+        if (opt.verbose) {
+            std::cerr << "LENGTH_CUTOFF = " << length_cutoff << std::endl;
+            std::cerr << "COVERAGE_CUTOFF = " << left_min << std::endl;
+        }
+        g.delete_erroneous_iterative(length_cutoff, left_min, opt.verbose);
+        avg_cov = avg_cov * (avg_len - kk + 1.0) / avg_len;
+        if (atoi(opt.bubble.c_str()) > 0) {
+            g.crush_bubble_iterative(avg_cov, opt.verbose);     // PREFIX_contigBubble.fa not restated
+        }
+        save_graph<W>(kk, all_reads);          // diff == 0: inserts nothing, keeps no read
+        if (W > 1) dh_size = table_size_for_memory(memory, W);
+        DHash<W> tmp;
+        tmp.resize(dh_size);
+        g.template save_contig<W>(kk, 1.0, tmp);
+        g.delete_all();
+        c.table = std::move(tmp);
+        c.count_reads_considering_table(kk, all_reads);
+        std::vector<Key<W>> sorted = c.sorted_keys(cutoff[num_k - 1]);
+        dh_size = c.load_kmers(cutoff[num_k - 1], dh_size);
+        g.set_k(kk);
+        g.make_initial(c.table, sorted);
+        g.save_contig_simple(contigs, avg_len / (avg_len - kk + 1.0));
+        g.save_junction(junctions, avg_len / (avg_len - kk + 1.0));
+    }
+};
+
+template <typename F> void dispatch_w(unsigned k, F &&f)
+{
+    if (k <= 32) f(std::integral_constant<int, 1>());
+    else if (k <= 64) f(std::integral_constant<int, 2>());
+    else if (k <= 96) f(std::integral_constant<int, 3>());
+    else if (k <= 128) f(std::integral_constant<int, 4>());
+    else if (k <= 160) f(std::integral_constant<int, 5>());
+    else throw std::runtime_error("k > 160 is outside the oracle's scope");
+}
+
+} // namespace
+
+int run_assemble(const AssembleOptions &opt, const ReadSet &input)
+{
+    Run run(opt);
+    run.memory = opt.memory_gb * 1000000000ull;
+    run.min_log_p_join = log(1.0 - pow(10.0, -opt.safety));
+    double bubble = atof(opt.bubble.c_str());
+    if (opt.repeat) bubble = 0.95;
+    std::get<0>(run.graphs).set_thresholds(bubble, opt.branch);
+    std::get<1>(run.graphs).set_thresholds(bubble, opt.branch);
+    std::get<2>(run.graphs).set_thresholds(bubble, opt.branch);
+    std::get<3>(run.graphs).set_thresholds(bubble, opt.branch);
+    std::get<4>(run.graphs).set_thresholds(bubble, opt.branch);
+    if (opt.repeat) throw std::runtime_error("-repeat (merge of three cutoff passes) is outside the oracle's scope");
+
+    run.all_reads = input;
+    run.reads = input;
+    run.k.assign(1, opt.k0);
+    dispatch_w(opt.k0, [&](auto w) { run.template initial<decltype(w)::value>(0.0); });
+    if (opt.kmer_occ_only) {
+        if (opt.verbose) std::cerr << "assemble completed!" << std::endl;
+        return 0;
+    }
+    for (u64 i = 1; i < run.num_k; ++i) {
+        const unsigned kp = run.k[i - 1], kn = run.k[i];
+        dispatch_w(kp, [&](auto wp) {
+            dispatch_w(kn, [&](auto wn) {
+                constexpr int WP = decltype(wp)::value, WN = decltype(wn)::value;
+                if constexpr (WN >= WP) run.template save_and_redo<WP, WN>(kn, kp, i);
+            });
+        });
+    }
+    const unsigned klast = run.k[run.num_k - 1];
+    dispatch_w(klast, [&](auto w) { run.template output_and_after<decltype(w)::value>(klast); });
+    const std::string out = opt.out_prefix + "_contig.fa";
+    print_contigs(out, run.contigs, 1.0, run.avg_len, klast, "seq", false);
+    print_contigs(out, run.junctions, 1.0, run.avg_len, klast, "junction", true);
+    if (opt.verbose) std::cerr << "assemble completed!" << std::endl;
+    return 0;
+}
+
+} // namespace pbo
