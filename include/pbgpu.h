@@ -1,0 +1,90 @@
+/*
+ * pbgpu.h -- C-ABI of libpbgpu.so: the MI355X (gfx950) implementation of Platanus_B's k-mer counting and
+ * de Bruijn graph hot path.
+ *
+ * The reference (rkajitani/Platanus_B v1.3.2) has no FFI/plugin interface: `Assemble` calls the C++ templates
+ * `Counter<KMER>` and `BruijnGraph<KMER>` directly.  Every entry point below therefore names
+ * the reference call it replaces (file:line relative to the reference tree).  A host that wants to be a
+ * drop-in for `platanus_b assemble` keeps assemble.cpp's control flow and swaps those calls for these.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative PB_E* code; pb_last_error(ctx) gives the text;
+ *   - no exceptions cross the boundary; plain pointers and sizes only;
+ *   - the library owns all device memory, the caller owns all host memory (buffers are caller-allocated,
+ *     sizes are obtained from the preceding call);
+ *   - calls on one context are not re-entrant (the reference's only concurrency contract is "-t OpenMP threads
+ *     inside one call", assemble.cpp:152);
+ *   - one context = one GPU.  Multi-GPU = one context per process/rank; the exchange step hands device
+ *     pointers to the caller's collective layer (RCCL through torch.distributed, or rccl directly).
+ *
+ * Key encoding (reference kmer.h:84-310, binstr.h:292-721): 2 bits/base A=0 C=1 G=2 T=3; a k-mer is a 2k-bit
+ * integer with its 5' base in the most significant position, stored as W = ceil(k/32) little-endian 64-bit
+ * words (word 0 = the 32 bases at the 3' end).  Keys handed over the boundary are canonical
+ * (min(forward, reverse complement), counter.h:429) unless stated otherwise.
+ */
+#ifndef PBGPU_H
+#define PBGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PB_OK            0
+#define PB_EINVAL       -1   /* bad argument / call order                                   */
+#define PB_EHIP         -2   /* HIP runtime error (text in pb_last_error)                   */
+#define PB_ENOMEM       -3   /* device or host allocation failed                            */
+#define PB_ERANGE       -4   /* k out of range (1..160), read too long (>= 500000, common.cpp:28) */
+#define PB_ENODEVICE    -5   /* no gfx950 device visible                                    */
+
+#define PB_MAX_K        160  /* KmerN<Binstr159>, assemble.cpp:182                          */
+#define PB_OCC_BINS     65535 /* occurrenceDistribution.resize(UINT16_MAX), counter.h:335   */
+#define PB_COUNT_MAX    65534 /* counts saturate at UINT16_MAX-1, counter.h:468-470         */
+
+typedef struct pb_ctx pb_ctx;
+
+/* ---- context ------------------------------------------------------------------------------------------- */
+int         pb_create(int device_id, pb_ctx **out);
+void        pb_destroy(pb_ctx *ctx);
+const char *pb_last_error(const pb_ctx *ctx);          /* ctx may be NULL: error of the last failed pb_create */
+/* name, CU count, HBM bytes of the context's device (for reports; not in the reference) */
+int         pb_device_info(const pb_ctx *ctx, char *name, size_t name_cap, int *n_cu, uint64_t *hbm_bytes);
+
+/* ---- reads: replaces the per-thread temp files readFP[] (assemble.cpp:790-986, common.h:426-448) ------- */
+/* Append reads given as one byte per base.  `ascii` != 0: bytes are FASTA/FASTQ letters and are converted
+ * on the device with the reference's Char2Bin table (common.h:256); otherwise bytes are codes 0..3, 4 = N.
+ * offsets[n_reads+1] are base offsets into `bases`.  Host buffers, copied before return.  On the device the
+ * reads are packed to 2 bits/base plus a 1-bit unknown-base mask (kernel K1).  Append order = the order of
+ * the reference's temp file 0 at -t 1 (file 1's reads, then file 2's, ...). */
+int pb_reads_append(pb_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads, int ascii);
+int pb_reads_clear(pb_ctx *ctx);
+int pb_reads_info(const pb_ctx *ctx, uint64_t *n_reads, uint64_t *n_bases);
+/* lengthDistribution (counter.h:328-333): hist[len] for len < hist_n; *sum_len, *n_reads for the mean */
+int pb_reads_length_hist(pb_ctx *ctx, uint64_t *hist, uint64_t hist_n);
+
+/* ---- Counter::makeKmerReadDistributionMT (counter.h:275-383): K2+K3+K4 -------------------------------- */
+/* Counts every N-free k-mer window of every resident read into a device occurrence table (canonical keys,
+ * counts saturating at 65534), then builds occurrenceDistribution.  Outputs (any may be NULL):
+ *   occ_hist[PB_OCC_BINS]  bin i = number of distinct k-mers seen i times (bin 0 unused), counter.h:482-507
+ *   max_occ                highest non-empty bin, counter.h:371-376
+ *   n_instances            windows counted;  n_distinct  distinct canonical k-mers                       */
+int pb_count(pb_ctx *ctx, unsigned k, uint64_t *occ_hist, uint64_t *max_occ, uint64_t *n_instances, uint64_t *n_distinct);
+
+/* ---- Counter::sortedKeyFromKmerFile + loadKmer (counter.h:916-951, 599-640): K4 compaction + K5 sort --- */
+/* Keeps the k-mers with count >= min_occ, sorted ascending by the 2k-bit key value; *n_keys = how many. */
+int pb_retain(pb_ctx *ctx, unsigned min_occ, uint64_t *n_keys);
+/* Copies the retained set out: keys[n_keys * W] (word-major per key: key i = keys[i*W .. i*W+W-1]), counts[n_keys]. */
+int pb_fetch_retained(pb_ctx *ctx, uint64_t *keys, uint16_t *counts);
+/* All distinct (key,count) of the last pb_count, unsorted (for exchange/merge and for tests). */
+int pb_fetch_all(pb_ctx *ctx, uint64_t *keys, uint32_t *counts, uint64_t cap, uint64_t *n);
+
+/* ---- timing of the last call, measured with HIP events on the library's stream ------------------------- */
+/* stage names: "pack", "count", "hist", "compact", "sort", "adjacency", ... ; returns PB_EINVAL if unknown */
+int pb_last_kernel_ms(const pb_ctx *ctx, const char *stage, float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PBGPU_H */

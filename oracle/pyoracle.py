@@ -1,0 +1,134 @@
+"""TEST INFRASTRUCTURE ONLY -- ctypes binding of oracle/liboracle.so (the CPU restatement).
+
+Importable from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg only; the product
+package platanus_b_amd never imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liboracle.so")
+REF_BIN = os.path.join(_HERE, "_ref", "platanus_b")
+_lib = None
+
+
+def build():
+    subprocess.run(["make", "-C", _HERE, "-j4", "oracle"], check=True, stdout=subprocess.DEVNULL)
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        l = C.CDLL(LIB_PATH)
+        vp = C.c_void_p
+        l.pbo_create.restype = vp
+        l.pbo_destroy.argtypes = [vp]
+        l.pbo_count.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint, C.c_uint64]
+        l.pbo_count.restype = C.c_uint64
+        l.pbo_occ_hist.argtypes = [vp, vp, C.POINTER(C.c_uint64)]
+        l.pbo_length_hist.argtypes = [vp, vp, C.c_uint64]
+        l.pbo_left_local_minimal_value.argtypes = [vp, C.c_uint64]
+        l.pbo_left_local_minimal_value.restype = C.c_uint64
+        l.pbo_num_distinct.argtypes = [vp]
+        l.pbo_num_distinct.restype = C.c_uint64
+        l.pbo_fetch_file_order.argtypes = [vp, vp, vp]
+        l.pbo_retain.argtypes = [vp, C.c_uint64]
+        l.pbo_retain.restype = C.c_uint64
+        l.pbo_fetch_retained.argtypes = [vp, vp, vp]
+        l.pbo_write_table_binary.argtypes = [vp, C.c_uint64, C.c_char_p]
+        l.pbo_write_occ_distribution.argtypes = [vp, C.c_char_p]
+        l.pbo_assemble.argtypes = [vp, vp, C.c_uint64, C.c_char_p, C.c_uint, C.c_uint, C.c_uint, C.c_uint64, C.c_int, C.c_int]
+        l.pbo_extend_kmer.argtypes = [C.c_double, C.c_double, C.c_double, C.c_uint64, C.c_double, C.c_uint, C.c_uint64,
+                                      C.c_uint64, vp, vp, C.c_uint]
+        l.pbo_extend_kmer.restype = C.c_uint64
+        _lib = l
+    return _lib
+
+
+class OracleCounter:
+    """Counter<KMER> of the reference at -t 1, restated on the CPU (oracle/src/counter.hpp)."""
+
+    def __init__(self):
+        self.l = lib()
+        self.h = C.c_void_p(self.l.pbo_create())
+        self.k = 0
+
+    def __del__(self):
+        try:
+            self.l.pbo_destroy(self.h)
+        except Exception:
+            pass
+
+    def count(self, codes: np.ndarray, offsets: np.ndarray, k: int, memory_bytes: int = 10 ** 9) -> int:
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        self.k = k
+        r = self.l.pbo_count(self.h, codes.ctypes.data, offsets.ctypes.data, offsets.size - 1, k, memory_bytes)
+        if r == 0:
+            raise RuntimeError("oracle count failed")
+        return r
+
+    def occ_hist(self):
+        h = np.zeros(65535, dtype=np.uint64)
+        mx = C.c_uint64()
+        self.l.pbo_occ_hist(self.h, h.ctypes.data, C.byref(mx))
+        return h, mx.value
+
+    def length_hist(self, n: int):
+        h = np.zeros(n, dtype=np.uint64)
+        self.l.pbo_length_hist(self.h, h.ctypes.data, n)
+        return h
+
+    def left_local_minimal_value(self, window: int = 1) -> int:
+        return self.l.pbo_left_local_minimal_value(self.h, window)
+
+    def file_order(self):
+        n = self.l.pbo_num_distinct(self.h)
+        W = (self.k + 31) // 32
+        keys = np.zeros((n, W), dtype=np.uint64)
+        counts = np.zeros(n, dtype=np.uint16)
+        self.l.pbo_fetch_file_order(self.h, keys.ctypes.data, counts.ctypes.data)
+        return keys, counts
+
+    def retain(self, min_occ: int):
+        n = self.l.pbo_retain(self.h, min_occ)
+        W = (self.k + 31) // 32
+        keys = np.zeros((n, W), dtype=np.uint64)
+        counts = np.zeros(n, dtype=np.uint16)
+        self.l.pbo_fetch_retained(self.h, keys.ctypes.data, counts.ctypes.data)
+        return keys, counts
+
+    def write_table_binary(self, min_occ: int, path: str):
+        if self.l.pbo_write_table_binary(self.h, min_occ, path.encode()) != 0:
+            raise RuntimeError("oracle write_table_binary failed")
+
+    def write_occ_distribution(self, path: str):
+        if self.l.pbo_write_occ_distribution(self.h, path.encode()) != 0:
+            raise RuntimeError("oracle write_occ_distribution failed")
+
+
+def assemble(codes: np.ndarray, offsets: np.ndarray, out_prefix: str, k0: int = 32, step: int = 10, n_cutoff: int = 0,
+             memory_gb: int = 1, kmer_occ_only: bool = False, verbose: bool = False) -> int:
+    codes = np.ascontiguousarray(codes, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    return lib().pbo_assemble(codes.ctypes.data, offsets.ctypes.data, offsets.size - 1, out_prefix.encode(), k0, step,
+                              n_cutoff, memory_gb, int(kmer_occ_only), int(verbose))
+
+
+def extend_kmer(min_log_p_join, avg_cov, avg_len, min_cov, max_k_ratio, k0, cutoff0, step):
+    ks = np.zeros(512, dtype=np.uint32)
+    cs = np.zeros(512, dtype=np.uint64)
+    n = lib().pbo_extend_kmer(min_log_p_join, avg_cov, avg_len, min_cov, max_k_ratio, k0, cutoff0, step,
+                              ks.ctypes.data, cs.ctypes.data, 512)
+    return [int(x) for x in ks[:n]], [int(x) for x in cs[:n]]
+
+
+def have_reference() -> bool:
+    return os.path.exists(REF_BIN) and os.access(REF_BIN, os.X_OK)

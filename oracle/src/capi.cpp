@@ -1,0 +1,162 @@
+// TEST INFRASTRUCTURE ONLY -- C entry points of the oracle for ctypes (tests/, smoke(), bench cpu_baseline).
+#include "assemble.hpp"
+#include "counter.hpp"
+#include "fastx.hpp"
+#include <cstring>
+#include <memory>
+
+using namespace pbo;
+
+namespace {
+struct Handle {
+    int W = 0;
+    unsigned k = 0;
+    std::unique_ptr<Counter<1>> c1; std::unique_ptr<Counter<2>> c2; std::unique_ptr<Counter<3>> c3;
+    std::unique_ptr<Counter<4>> c4; std::unique_ptr<Counter<5>> c5;
+    std::vector<u64> sorted;     // n * W
+    std::vector<u16> sorted_counts;
+    u64 dh_size = 0;
+};
+template <int W> Counter<W> &get(Handle *h);
+template <> Counter<1> &get<1>(Handle *h) { return *h->c1; }
+template <> Counter<2> &get<2>(Handle *h) { return *h->c2; }
+template <> Counter<3> &get<3>(Handle *h) { return *h->c3; }
+template <> Counter<4> &get<4>(Handle *h) { return *h->c4; }
+template <> Counter<5> &get<5>(Handle *h) { return *h->c5; }
+
+template <int W> void do_count(Handle *h, const ReadSet &rs, unsigned k, u64 memory)
+{
+    Counter<W> &c = get<W>(h);
+    h->dh_size = c.count_reads(k, rs, memory);
+}
+template <int W> void do_retain(Handle *h, u64 min_occ)
+{
+    Counter<W> &c = get<W>(h);
+    // (key,count) pairs with count >= min_occ sorted by key (sorted_keys() + the counts that go with them)
+    std::vector<std::pair<Key<W>, u16>> v;
+    for (size_t i = 0; i < c.kmer_keys.size(); ++i) if (c.kmer_vals[i] >= min_occ) v.push_back({c.kmer_keys[i], c.kmer_vals[i]});
+    std::sort(v.begin(), v.end(), [](const std::pair<Key<W>, u16> &a, const std::pair<Key<W>, u16> &b) { return a.first < b.first; });
+    h->sorted.resize(v.size() * W);
+    h->sorted_counts.resize(v.size());
+    for (size_t i = 0; i < v.size(); ++i) {
+        for (int w = 0; w < W; ++w) h->sorted[i * W + w] = v[i].first.w[w];
+        h->sorted_counts[i] = v[i].second;
+    }
+}
+} // namespace
+
+extern "C" {
+
+void *pbo_create() { return new Handle(); }
+void pbo_destroy(void *p) { delete (Handle *)p; }
+
+// counter.h:275-383 at -t 1.  codes: 0..3, 4 = N.  Returns doubleHashSize, or 0 on error.
+unsigned long long pbo_count(void *p, const uint8_t *codes, const unsigned long long *off, unsigned long long n_reads,
+                             unsigned k, unsigned long long memory_bytes)
+{
+    Handle *h = (Handle *)p;
+    ReadSet rs;
+    rs.bases.assign(codes + off[0], codes + off[n_reads]);
+    rs.off.resize(n_reads + 1);
+    for (u64 i = 0; i <= n_reads; ++i) rs.off[i] = off[i] - off[0];
+    h->k = k;
+    h->W = words_for_k(k);
+    try {
+        switch (h->W) {
+        case 1: h->c1.reset(new Counter<1>()); do_count<1>(h, rs, k, memory_bytes); break;
+        case 2: h->c2.reset(new Counter<2>()); do_count<2>(h, rs, k, memory_bytes); break;
+        case 3: h->c3.reset(new Counter<3>()); do_count<3>(h, rs, k, memory_bytes); break;
+        case 4: h->c4.reset(new Counter<4>()); do_count<4>(h, rs, k, memory_bytes); break;
+        case 5: h->c5.reset(new Counter<5>()); do_count<5>(h, rs, k, memory_bytes); break;
+        default: return 0;
+        }
+    } catch (...) { return 0; }
+    return h->dh_size;
+}
+
+#define DISPATCH(h, expr) switch ((h)->W) { case 1: { auto &c = get<1>(h); expr; } break; case 2: { auto &c = get<2>(h); expr; } break; \
+    case 3: { auto &c = get<3>(h); expr; } break; case 4: { auto &c = get<4>(h); expr; } break; default: { auto &c = get<5>(h); expr; } break; }
+
+void pbo_occ_hist(void *p, unsigned long long *hist /*65535*/, unsigned long long *max_occ)
+{
+    Handle *h = (Handle *)p;
+    DISPATCH(h, { for (int i = 0; i < 65535; ++i) hist[i] = c.occ_hist[i]; *max_occ = c.max_occ; });
+}
+void pbo_length_hist(void *p, unsigned long long *hist, unsigned long long n)
+{
+    Handle *h = (Handle *)p;
+    DISPATCH(h, { for (u64 i = 0; i < n; ++i) hist[i] = i < c.length_hist.size() ? c.length_hist[i] : 0; });
+}
+unsigned long long pbo_left_local_minimal_value(void *p, unsigned long long window)
+{
+    Handle *h = (Handle *)p; u64 r = 0;
+    DISPATCH(h, r = c.left_local_minimal_value(window));
+    return r;
+}
+unsigned long long pbo_num_distinct(void *p)
+{
+    Handle *h = (Handle *)p; u64 r = 0;
+    DISPATCH(h, r = c.kmer_keys.size());
+    return r;
+}
+// kmerFP order (counter.h:482-507)
+void pbo_fetch_file_order(void *p, unsigned long long *keys, uint16_t *counts)
+{
+    Handle *h = (Handle *)p;
+    DISPATCH(h, { const int W = (int)(sizeof(c.kmer_keys[0]) / 8);
+        for (size_t i = 0; i < c.kmer_keys.size(); ++i) { for (int w = 0; w < W; ++w) keys[i * W + w] = c.kmer_keys[i].w[w]; counts[i] = c.kmer_vals[i]; } });
+}
+unsigned long long pbo_retain(void *p, unsigned long long min_occ)
+{
+    Handle *h = (Handle *)p;
+    switch (h->W) { case 1: do_retain<1>(h, min_occ); break; case 2: do_retain<2>(h, min_occ); break; case 3: do_retain<3>(h, min_occ); break;
+                    case 4: do_retain<4>(h, min_occ); break; default: do_retain<5>(h, min_occ); break; }
+    return h->sorted_counts.size();
+}
+void pbo_fetch_retained(void *p, unsigned long long *keys, uint16_t *counts)
+{
+    Handle *h = (Handle *)p;
+    if (!h->sorted.empty()) memcpy(keys, h->sorted.data(), h->sorted.size() * 8);
+    if (!h->sorted_counts.empty()) memcpy(counts, h->sorted_counts.data(), h->sorted_counts.size() * 2);
+}
+// loadKmer + outputOccurrenceTableBinary (counter.h:599-640,954-963); consumes the kmer file
+int pbo_write_table_binary(void *p, unsigned long long min_occ, const char *path)
+{
+    Handle *h = (Handle *)p;
+    try { DISPATCH(h, { c.load_kmers(min_occ, h->dh_size); c.write_table_binary(path); }); } catch (...) { return -1; }
+    return 0;
+}
+int pbo_write_occ_distribution(void *p, const char *path)
+{
+    Handle *h = (Handle *)p;
+    try { DISPATCH(h, c.write_occ_distribution(path)); } catch (...) { return -1; }
+    return 0;
+}
+
+// whole pipeline on in-memory reads; argv-style options as for `platanus_b assemble`
+int pbo_assemble(const uint8_t *codes, const unsigned long long *off, unsigned long long n_reads, const char *out_prefix,
+                 unsigned k0, unsigned step, unsigned n_cutoff, unsigned long long memory_gb, int kmer_occ_only, int verbose)
+{
+    ReadSet rs;
+    rs.bases.assign(codes + off[0], codes + off[n_reads]);
+    rs.off.resize(n_reads + 1);
+    for (u64 i = 0; i <= n_reads; ++i) rs.off[i] = off[i] - off[0];
+    AssembleOptions o;
+    o.out_prefix = out_prefix; o.k0 = k0; o.step = step; o.n_cutoff = n_cutoff; o.memory_gb = memory_gb;
+    o.kmer_occ_only = kmer_occ_only != 0; o.verbose = verbose != 0;
+    try { return run_assemble(o, rs); } catch (const std::exception &e) { fprintf(stderr, "oracle: %s\n", e.what()); return -1; }
+}
+
+// schedule helper (assemble.cpp:657-736) for host-logic tests
+unsigned long long pbo_extend_kmer(double min_log_p_join, double avg_cov, double avg_len, unsigned long long min_cov, double max_k_ratio,
+                                   unsigned k0, unsigned long long cutoff0, unsigned long long step, unsigned *k_out,
+                                   unsigned long long *cutoff_out, unsigned cap)
+{
+    std::vector<unsigned> k{k0};
+    std::vector<u64> c{cutoff0};
+    const u64 n = extend_kmer(min_log_p_join, avg_cov, avg_len, min_cov, max_k_ratio, k, c, step, false);
+    for (u64 i = 0; i < n && i < cap; ++i) { k_out[i] = k[i]; cutoff_out[i] = c[i]; }
+    return n;
+}
+
+} // extern "C"
