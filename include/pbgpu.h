@@ -80,6 +80,22 @@ int pb_fetch_retained(pb_ctx *ctx, uint64_t *keys, uint16_t *counts);
 /* All distinct (key,count) of the last pb_count, unsorted (for exchange/merge and for tests). */
 int pb_fetch_all(pb_ctx *ctx, uint64_t *keys, uint32_t *counts, uint64_t cap, uint64_t *n);
 
+/* ---- X1: multi-GPU merge of per-GPU occurrence tables (no reference counterpart: OpenMP threads share one
+ * table behind 1024 stripe locks, counter.h:458-476).  Owner exchange: a key belongs to the rank
+ * owner = ((key.word0 & 1023) * n_parts) >> 10, i.e. a contiguous range of the reference's 1024 stripes.
+ *   pb_export_begin  buckets every (key,count) of the local table by owner on the device; part_counts[n_parts]
+ *   pb_export_copy   copies the bucketed records (owner 0 first) into CALLER device buffers
+ *                    dev_keys u64[total*W], dev_counts u32[total] -- e.g. torch tensors that then go through
+ *                    torch.distributed.all_to_all_single (RCCL over xGMI)
+ *   pb_merge_begin/add/end  owner side: fresh table, add received records (device pointers), then the merged
+ *                    table becomes the context's table (pb_retain etc. work on it) and its histogram is returned;
+ *                    the caller all-reduces the histograms (sum) to get the global occurrenceDistribution. */
+int pb_export_begin(pb_ctx *ctx, int n_parts, uint64_t *part_counts);
+int pb_export_copy(pb_ctx *ctx, void *dev_keys, void *dev_counts);
+int pb_merge_begin(pb_ctx *ctx, unsigned k, uint64_t expected_records);
+int pb_merge_add(pb_ctx *ctx, const void *dev_keys, const void *dev_counts, uint64_t n);
+int pb_merge_end(pb_ctx *ctx, uint64_t *occ_hist, uint64_t *max_occ, uint64_t *n_distinct);
+
 /* ---- timing of the last call, measured with HIP events on the library's stream ------------------------- */
 /* stage names: "pack", "count", "hist", "compact", "sort", "adjacency", ... ; returns PB_EINVAL if unknown */
 int pb_last_kernel_ms(const pb_ctx *ctx, const char *stage, float *ms);

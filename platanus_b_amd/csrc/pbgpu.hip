@@ -51,6 +51,11 @@ struct pb_ctx {
     DevBuf ret_keys, ret_counts;        // u64[n*W], u16[n]
     u64 n_retained = 0;
 
+    // owner exchange (X1)
+    DevBuf exp_keys, exp_counts, merge_table;
+    u64 exp_total = 0, merge_cap = 0;
+    unsigned exp_parts = 0;
+
     // scratch
     DevBuf scratch[6];
 };
@@ -298,6 +303,90 @@ compact_kernel(TableView<W> table, u32 min_occ, u64 *__restrict__ out_keys, u32 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// X1 (no reference counterpart: the reference's threads share one table).  Multi-GPU merge of per-GPU
+// occurrence tables = owner exchange: every (key,count) record goes to the GPU that owns the key's
+// stripe, owner = ((key & 1023) * n_parts) >> 10 -- the reference's own stripe function (counter.h:461).
+//   part_count_kernel   : records per owner (LDS counters, one global add per owner per block)
+//   part_scatter_kernel : bucketed copy; a block reserves one range per owner, lanes rank inside via LDS
+//   merge_kernel        : owner side, table_add(key, count) -- counts are commutative and saturate at
+//                         read-out (counter.h:468-470), so the union of owner shards is the -t 1 table
+// ------------------------------------------------------------------------------------------------------
+#define PB_MAX_PARTS 64
+template <int W>
+__device__ __forceinline__ bool slot_record(const TableView<W> &t, u64 s, u32 &c, const u64 *&slot)
+{
+    slot = t.slots + s * PB_SLOT_WORDS(W);
+    bool occ;
+    if (W == 1) { occ = slot[0] != PB_EMPTY_KEY; c = (u32)slot[1]; }
+    else { const u64 meta = slot[W]; occ = (meta >> 32) != 0; c = (u32)meta; }
+    return occ && c != 0;
+}
+
+template <int W>
+__global__ void __launch_bounds__(256)
+part_count_kernel(TableView<W> table, unsigned n_parts, u64 *__restrict__ part_counts)
+{
+    __shared__ u32 lc[PB_MAX_PARTS];
+    if (threadIdx.x < PB_MAX_PARTS) lc[threadIdx.x] = 0;
+    __syncthreads();
+    const u64 cap = table.mask + 1, stride = (u64)gridDim.x * blockDim.x;
+    for (u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x; s < cap; s += stride) {
+        u32 c; const u64 *slot;
+        if (!slot_record<W>(table, s, c, slot)) continue;
+        atomicAdd(&lc[(unsigned)(((slot[0] & 1023) * n_parts) >> 10)], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < n_parts && lc[threadIdx.x]) atomicAdd(&part_counts[threadIdx.x], (u64)lc[threadIdx.x]);
+}
+
+template <int W>
+__global__ void __launch_bounds__(256)
+part_scatter_kernel(TableView<W> table, unsigned n_parts, u64 *__restrict__ cursors /* start offsets, advanced */,
+                    u64 *__restrict__ out_keys, u32 *__restrict__ out_counts)
+{
+    __shared__ u32 lc[PB_MAX_PARTS];
+    __shared__ u64 lbase[PB_MAX_PARTS];
+    const u64 cap = table.mask + 1, stride = (u64)gridDim.x * blockDim.x;
+    const u64 n_iter = (cap + stride - 1) / stride;
+    u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (u64 it = 0; it < n_iter; ++it, s += stride) {
+        if (threadIdx.x < PB_MAX_PARTS) lc[threadIdx.x] = 0;
+        __syncthreads();
+        u32 c = 0; const u64 *slot = nullptr;
+        const bool take = s < cap && slot_record<W>(table, s, c, slot);
+        unsigned owner = 0; u32 local = 0;
+        if (take) { owner = (unsigned)(((slot[0] & 1023) * n_parts) >> 10); local = atomicAdd(&lc[owner], 1u); }
+        __syncthreads();
+        if (threadIdx.x < n_parts && lc[threadIdx.x]) lbase[threadIdx.x] = atomicAdd(&cursors[threadIdx.x], (u64)lc[threadIdx.x]);
+        __syncthreads();
+        if (take) {
+            const u64 pos = lbase[owner] + local;
+#pragma unroll
+            for (int i = 0; i < W; ++i) out_keys[pos * W + i] = slot[i];
+            out_counts[pos] = c > PB_COUNT_MAX ? PB_COUNT_MAX : c;
+        }
+        __syncthreads();
+    }
+}
+
+template <int W>
+__global__ void __launch_bounds__(256)
+merge_kernel(const u64 *__restrict__ keys, const u32 *__restrict__ counts, u64 n, TableView<W> table, u32 max_probe,
+             u64 *__restrict__ scalars)
+{
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    bool ovf = false;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        DKey<W> key;
+#pragma unroll
+        for (int w = 0; w < W; ++w) key.w[w] = keys[i * W + w];
+        if (!table_add<W>(table, key, counts[i], max_probe)) ovf = true;
+    }
+    if (ovf) scalars[1] = 1;
+}
+
 // ------------------------------------------------------------------------------------------------------
 // K5: stable LSD radix sort of (u64 key, u32 value) pairs, 8 bits per pass.
 //   rs_count   : per-tile digit histogram              -> counts[digit * n_tiles + tile]
@@ -484,7 +573,7 @@ void pb_destroy(pb_ctx *ctx)
     (void)hipSetDevice(ctx->dev);
     (void)hipStreamSynchronize(ctx->stream);
     release(ctx->packed); release(ctx->nmask); release(ctx->table); release(ctx->d_hist); release(ctx->d_scalars);
-    release(ctx->ret_keys); release(ctx->ret_counts);
+    release(ctx->ret_keys); release(ctx->ret_counts); release(ctx->exp_keys); release(ctx->exp_counts); release(ctx->merge_table);
     for (auto &s : ctx->scratch) release(s);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
@@ -591,8 +680,12 @@ static int count_impl(pb_ctx *ctx, unsigned k)
         ctx->table_cap = cap;
         TableView<W> tv{(u64 *)ctx->table.p, cap - 1};
         HIPCHK(hipMemsetAsync(ctx->d_scalars.p, 0, 16 * 8, ctx->stream));
+        {
+            StageTimer ti(ctx, "table_init");
+            table_init_kernel<W><<<grid_for(cap * PB_SLOT_WORDS(W), 256, 256 * 32), 256, 0, ctx->stream>>>(tv.slots, cap);
+            if ((rc = ti.stop()) != PB_OK) return rc;
+        }
         StageTimer tm(ctx, "count");
-        table_init_kernel<W><<<grid_for(cap * PB_SLOT_WORDS(W), 256, 256 * 32), 256, 0, ctx->stream>>>(tv.slots, cap);
         if (ctx->stream_len >= k) {
             count_kernel<W><<<grid_for(ctx->stream_len, 256, getenv("PB_GRIDCAP") ? atoi(getenv("PB_GRIDCAP")) : 256 * 32), 256, 0, ctx->stream>>>(
                 (const u64 *)ctx->packed.p, (const u64 *)ctx->nmask.p, ctx->stream_len, k, tv, 256u, (u64 *)ctx->d_scalars.p);
@@ -754,6 +847,144 @@ int pb_last_kernel_ms(const pb_ctx *ctx, const char *stage, float *ms)
     auto it = ctx->stage_ms.find(stage);
     if (it == ctx->stage_ms.end()) return PB_EINVAL;
     *ms = it->second;
+    return PB_OK;
+}
+
+} // extern "C"
+
+template <int W>
+static int export_impl(pb_ctx *ctx, unsigned n_parts, uint64_t *part_counts)
+{
+    int rc;
+    TableView<W> tv{(u64 *)ctx->table.p, ctx->table_cap - 1};
+    if ((rc = ensure(ctx, ctx->d_scalars, 16 * 8)) != PB_OK) return rc;
+    DevBuf &pc = ctx->scratch[0];
+    if ((rc = ensure(ctx, pc, PB_MAX_PARTS * 8 * 2)) != PB_OK) return rc;
+    HIPCHK(hipMemsetAsync(pc.p, 0, PB_MAX_PARTS * 8 * 2, ctx->stream));
+    StageTimer tm(ctx, "export");
+    part_count_kernel<W><<<grid_for(ctx->table_cap, 256, 256 * 8), 256, 0, ctx->stream>>>(tv, n_parts, (u64 *)pc.p);
+    u64 h[PB_MAX_PARTS];
+    HIPCHK(hipMemcpyAsync(h, pc.p, n_parts * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    u64 cur[PB_MAX_PARTS], total = 0;
+    for (unsigned i = 0; i < n_parts; ++i) { cur[i] = total; total += h[i]; part_counts[i] = h[i]; }
+    ctx->exp_total = total;
+    ctx->exp_parts = n_parts;
+    if ((rc = ensure(ctx, ctx->exp_keys, std::max<u64>(total, 1) * W * 8)) != PB_OK) return rc;
+    if ((rc = ensure(ctx, ctx->exp_counts, std::max<u64>(total, 1) * 4)) != PB_OK) return rc;
+    u64 *cursors = (u64 *)pc.p + PB_MAX_PARTS;
+    HIPCHK(hipMemcpyAsync(cursors, cur, n_parts * 8, hipMemcpyHostToDevice, ctx->stream));
+    part_scatter_kernel<W><<<grid_for(ctx->table_cap, 256, 256 * 8), 256, 0, ctx->stream>>>(tv, n_parts, cursors, (u64 *)ctx->exp_keys.p,
+                                                                                         (u32 *)ctx->exp_counts.p);
+    HIPCHK(hipGetLastError());
+    return tm.stop();
+}
+
+template <int W>
+static int merge_add_impl(pb_ctx *ctx, const void *dev_keys, const void *dev_counts, u64 n)
+{
+    int rc;
+    TableView<W> tv{(u64 *)ctx->merge_table.p, ctx->merge_cap - 1};
+    HIPCHK(hipMemsetAsync(ctx->d_scalars.p, 0, 16 * 8, ctx->stream));
+    StageTimer tm(ctx, "merge");
+    if (n) merge_kernel<W><<<grid_for(n, 256, 256 * 16), 256, 0, ctx->stream>>>((const u64 *)dev_keys, (const u32 *)dev_counts, n, tv, 1024u,
+                                                                              (u64 *)ctx->d_scalars.p);
+    HIPCHK(hipGetLastError());
+    if ((rc = tm.stop()) != PB_OK) return rc;
+    u64 sc[2];
+    HIPCHK(hipMemcpyAsync(sc, ctx->d_scalars.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (sc[1]) { ctx->err = "merge table overflow (expected_records too small)"; return PB_ENOMEM; }
+    return PB_OK;
+}
+
+template <int W>
+static int merge_begin_impl(pb_ctx *ctx, u64 cap)
+{
+    int rc;
+    if ((rc = ensure(ctx, ctx->merge_table, cap * PB_SLOT_WORDS(W) * 8)) != PB_OK) return rc;
+    ctx->merge_cap = cap;
+    table_init_kernel<W><<<grid_for(cap * PB_SLOT_WORDS(W), 256, 256 * 32), 256, 0, ctx->stream>>>((u64 *)ctx->merge_table.p, cap);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return PB_OK;
+}
+
+template <int W>
+static int hist_only_impl(pb_ctx *ctx)
+{
+    int rc;
+    if ((rc = ensure(ctx, ctx->d_hist, 65536 * 8)) != PB_OK) return rc;
+    TableView<W> tv{(u64 *)ctx->table.p, ctx->table_cap - 1};
+    HIPCHK(hipMemsetAsync(ctx->d_hist.p, 0, 65536 * 8, ctx->stream));
+    StageTimer tm(ctx, "hist");
+    hist_kernel<W><<<grid_for(ctx->table_cap, 256, 256 * 8), 256, 0, ctx->stream>>>(tv, (u64 *)ctx->d_hist.p);
+    HIPCHK(hipGetLastError());
+    return tm.stop();
+}
+
+#define PB_DISPATCH_W(ctx, fn, ...)                                   \
+    ((ctx)->W == 1 ? fn<1>(__VA_ARGS__) : (ctx)->W == 2 ? fn<2>(__VA_ARGS__) : (ctx)->W == 3 ? fn<3>(__VA_ARGS__) \
+     : (ctx)->W == 4 ? fn<4>(__VA_ARGS__) : fn<5>(__VA_ARGS__))
+
+extern "C" {
+
+int pb_export_begin(pb_ctx *ctx, int n_parts, uint64_t *part_counts)
+{
+    if (!ctx || !part_counts || n_parts < 1 || n_parts > PB_MAX_PARTS || ctx->W == 0 || !ctx->table.p) return PB_EINVAL;
+    (void)hipSetDevice(ctx->dev);
+    return PB_DISPATCH_W(ctx, export_impl, ctx, (unsigned)n_parts, part_counts);
+}
+
+int pb_export_copy(pb_ctx *ctx, void *dev_keys, void *dev_counts)
+{
+    if (!ctx || ctx->exp_parts == 0) return PB_EINVAL;
+    (void)hipSetDevice(ctx->dev);
+    if (ctx->exp_total) {
+        HIPCHK(hipMemcpyAsync(dev_keys, ctx->exp_keys.p, ctx->exp_total * ctx->W * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(dev_counts, ctx->exp_counts.p, ctx->exp_total * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return PB_OK;
+}
+
+int pb_merge_begin(pb_ctx *ctx, unsigned k, uint64_t expected_records)
+{
+    if (!ctx || k < 1 || k > PB_MAX_K) return PB_EINVAL;
+    (void)hipSetDevice(ctx->dev);
+    int rc;
+    ctx->k = k;
+    ctx->W = (int)((k + 31) / 32);
+    if ((rc = ensure(ctx, ctx->d_scalars, 16 * 8)) != PB_OK) return rc;
+    u64 cap = 1ull << 16;
+    while (cap < expected_records * 2) cap <<= 1;
+    return PB_DISPATCH_W(ctx, merge_begin_impl, ctx, cap);
+}
+
+int pb_merge_add(pb_ctx *ctx, const void *dev_keys, const void *dev_counts, uint64_t n)
+{
+    if (!ctx || ctx->merge_cap == 0 || (n && (!dev_keys || !dev_counts))) return PB_EINVAL;
+    (void)hipSetDevice(ctx->dev);
+    return PB_DISPATCH_W(ctx, merge_add_impl, ctx, dev_keys, dev_counts, (u64)n);
+}
+
+int pb_merge_end(pb_ctx *ctx, uint64_t *occ_hist, uint64_t *max_occ, uint64_t *n_distinct)
+{
+    if (!ctx || ctx->merge_cap == 0) return PB_EINVAL;
+    (void)hipSetDevice(ctx->dev);
+    std::swap(ctx->table, ctx->merge_table);
+    ctx->table_cap = ctx->merge_cap;
+    ctx->merge_cap = 0;
+    ctx->n_retained = 0;
+    int rc = PB_DISPATCH_W(ctx, hist_only_impl, ctx);
+    if (rc != PB_OK) return rc;
+    std::vector<u64> h(65536);
+    HIPCHK(hipMemcpyAsync(h.data(), ctx->d_hist.p, 65536 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->n_distinct = h[65535];
+    if (occ_hist) for (int i = 0; i < PB_OCC_BINS; ++i) occ_hist[i] = h[i];
+    if (max_occ) { *max_occ = 0; for (int i = PB_COUNT_MAX; i > 0; --i) if (h[i]) { *max_occ = (u64)i; break; } }
+    if (n_distinct) *n_distinct = ctx->n_distinct;
     return PB_OK;
 }
 

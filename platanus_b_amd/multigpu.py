@@ -1,0 +1,74 @@
+"""Multi-GPU merge of per-GPU occurrence tables: owner exchange over torch.distributed.
+
+One process per GPU.  Reads are range-partitioned over ranks; every rank counts its reads into a private
+device table; every (key,count) record then travels to the rank that owns the key's stripe,
+owner = ((key.word0 & 1023) * world) >> 10 (the reference's stripe function, counter.h:461), in ONE
+all_to_all over xGMI (backend "nccl" is RCCL on ROCm); owners add the counts (saturating at read-out,
+counter.h:468-470), so the union of the owner shards is exactly the table a single process would have built.
+Histograms (and read-length histograms) are summed with all_reduce.
+
+The collective layer only sees flat integer tensors, so the same code runs over gloo with CPU tensors --
+that is how tests/test_multigpu_gloo.py covers the N>1 path without a GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+
+def owner_of(key_word0: np.ndarray, world: int) -> np.ndarray:
+    return (((key_word0 & np.uint64(1023)) * np.uint64(world)) >> np.uint64(10)).astype(np.int64)
+
+
+def exchange_records(dist, torch, keys, counts, send_counts, W: int):
+    """keys: int64 tensor [n*W] bucketed by owner, counts: int32 tensor [n], send_counts: list[int] per owner.
+    Returns (recv_keys, recv_counts, recv_counts_per_rank)."""
+    world = dist.get_world_size()
+    dev = keys.device
+    sc = torch.tensor(send_counts, dtype=torch.int64, device=dev)
+    rc = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_to_all_single(rc, sc)
+    recv = [int(x) for x in rc.tolist()]
+    rk = torch.empty(sum(recv) * W, dtype=torch.int64, device=dev)
+    rcnt = torch.empty(sum(recv), dtype=torch.int32, device=dev)
+    dist.all_to_all_single(rk, keys, [r * W for r in recv], [s * W for s in send_counts])
+    dist.all_to_all_single(rcnt, counts, recv, list(send_counts))
+    return rk, rcnt, recv
+
+
+def exchange_and_merge(g, dist, world: int, rank: int):
+    """g: GpuCounter that has just counted this rank's reads.  After the call g's table is this rank's owner
+    shard of the global table and g.occ_hist / g.max_occ / g.n_distinct describe the GLOBAL distribution."""
+    import torch
+    from .binding import PB_OCC_BINS, words_for_k
+    lib, h = g.lib, g.h
+    W = words_for_k(g.k)
+    part = (C.c_uint64 * world)()
+    g._chk(lib.pb_export_begin(h, world, part))
+    send = [int(x) for x in part]
+    n = sum(send)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    keys = torch.empty(max(n, 1) * W, dtype=torch.int64, device=dev)
+    counts = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    g._chk(lib.pb_export_copy(h, C.c_void_p(keys.data_ptr()), C.c_void_p(counts.data_ptr())))
+    rk, rcnt, recv = exchange_records(dist, torch, keys[:n * W], counts[:n], send, W)
+    torch.cuda.synchronize()                 # the library runs on its own stream
+    total = sum(recv)
+    g._chk(lib.pb_merge_begin(h, g.k, max(total, 1)))
+    g._chk(lib.pb_merge_add(h, C.c_void_p(rk.data_ptr()), C.c_void_p(rcnt.data_ptr()), total))
+    hist = np.zeros(PB_OCC_BINS, dtype=np.uint64)
+    mx, nd = C.c_uint64(), C.c_uint64()
+    g._chk(lib.pb_merge_end(h, hist.ctypes.data, C.byref(mx), C.byref(nd)))
+    th = torch.from_numpy(hist.astype(np.int64)).to(dev)
+    dist.all_reduce(th)
+    ghist = th.cpu().numpy().astype(np.uint64)
+    g.occ_hist = ghist
+    nz = np.nonzero(ghist[1:65535])[0]
+    g.max_occ = int(nz[-1]) + 1 if nz.size else 0
+    tn = torch.tensor([nd.value], dtype=torch.int64, device=dev)
+    dist.all_reduce(tn)
+    g.n_distinct_local = nd.value
+    g.n_distinct = int(tn.item())
+    return ghist

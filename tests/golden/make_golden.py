@@ -1,0 +1,78 @@
+"""Regenerate the golden fixtures from the REAL reference binary (oracle/_ref/platanus_b, built by
+oracle/Makefile from /root/reference).  Runs only where /root/reference exists; the fixtures it writes
+are plain data (inputs are regenerated from the seeded generator, outputs are the reference's files).
+
+    python tests/golden/make_golden.py
+"""
+import hashlib
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from platanus_b_amd import synth  # noqa: E402
+
+REF = os.path.join(ROOT, "oracle", "_ref", "platanus_b")
+
+# name -> generator parameters + the reference command lines whose outputs are kept
+CASES = {
+    "g5k": dict(genome=5000, cov=30, seed=3, err=0.01, n_rate=0.002,
+                runs={"multik": ["-k", "32", "-t", "1", "-m", "1"],
+                      "occ_n2": ["-k", "32", "-t", "1", "-m", "1", "-n", "2", "-kmer_occ_only"],
+                      "k21_s0": ["-k", "21", "-s", "0", "-t", "1", "-m", "1"]}),
+    "c1": dict(genome=50_000, cov=50, seed=1, err=0.005, n_rate=0.0,
+               runs={"multik": ["-k", "32", "-t", "1", "-m", "1"],
+                     "occ": ["-k", "32", "-t", "1", "-m", "1", "-kmer_occ_only"],
+                     "s0": ["-k", "32", "-s", "0", "-t", "1", "-m", "1"]}),
+    "c2": dict(genome=200_000, cov=40, seed=7, err=0.01, n_rate=0.001,
+               runs={"multik_n2": ["-k", "32", "-t", "1", "-m", "1", "-n", "2"]}),
+    "k45": dict(genome=20_000, cov=40, seed=11, err=0.005, n_rate=0.0,
+                runs={"multik_k45": ["-k", "45", "-t", "1", "-m", "1"]}),
+}
+KEEP_WHOLE_BELOW = 400_000      # bytes; larger outputs are pinned by md5 only
+
+
+def md5(path):
+    h = hashlib.md5()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def main():
+    if not os.path.exists(REF):
+        sys.exit("oracle/_ref/platanus_b missing: run `make -C oracle ref` where /root/reference exists")
+    manifest = {}
+    for name, c in CASES.items():
+        tmp = tempfile.mkdtemp(prefix="golden_")
+        try:
+            synth.write_pair_files(os.path.join(tmp, "in"), c["genome"], c["cov"], c["seed"], err=c["err"], n_rate=c["n_rate"])
+            manifest[name] = {k: c[k] for k in ("genome", "cov", "seed", "err", "n_rate")}
+            manifest[name]["runs"] = {}
+            for run, args in c["runs"].items():
+                d = os.path.join(tmp, run)
+                os.makedirs(d)
+                subprocess.run([REF, "assemble", *args, "-o", "out", "-f", "../in_1.fq", "../in_2.fq"], cwd=d, check=True,
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                files = {}
+                for fn in sorted(os.listdir(d)):
+                    p = os.path.join(d, fn)
+                    files[fn] = {"md5": md5(p), "bytes": os.path.getsize(p)}
+                    if os.path.getsize(p) <= KEEP_WHOLE_BELOW:
+                        shutil.copy(p, os.path.join(HERE, f"{name}.{run}.{fn}"))
+                manifest[name]["runs"][run] = {"args": args, "files": files}
+                print(name, run, {k: v["bytes"] for k, v in files.items()})
+        finally:
+            shutil.rmtree(tmp)
+    with open(os.path.join(HERE, "manifest.json"), "w") as f:
+        json.dump(manifest, f, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()

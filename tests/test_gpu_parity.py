@@ -1,0 +1,197 @@
+"""Parity tests proper: the HIP path (through the C-ABI, include/pbgpu.h) against the oracle and the golden
+vectors.  Integer work: the bar is bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, case_reads
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    from platanus_b_amd.binding import GpuCounter
+    return GpuCounter
+
+
+def _oracle(codes, off, k, oracle_built):
+    oc = oracle_built.OracleCounter()
+    oc.count(codes.reshape(-1), off, k)
+    return oc
+
+
+@pytest.mark.parametrize("k", [32, 21, 1, 31, 33, 42, 64, 65, 75, 96, 97, 108, 128, 129, 150])
+def test_count_matches_oracle_all_key_widths(k, gpu, oracle_built):
+    from platanus_b_amd import synth
+    r1, r2 = synth.make_reads(30_000, 40, seed=20 + k, n_rate=0.002)
+    codes = np.concatenate([r1, r2])
+    n, L = codes.shape
+    off = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
+    oc = _oracle(codes, off, k, oracle_built)
+    ohist, omax = oc.occ_hist()
+    g = gpu(0)
+    g.reads_append_matrix(r1)          # two appends: the second starts in the middle of a packed word
+    g.reads_append_matrix(r2)
+    hist = g.make_kmer_read_distribution(k)
+    assert np.array_equal(hist, ohist)
+    assert g.max_occ == omax
+    assert g.n_distinct == int(ohist.sum())
+    assert g.n_instances == int((np.arange(65535, dtype=np.uint64) * ohist).sum())
+    assert np.array_equal(g.length_hist(200), oc.length_hist(200))
+    for cutoff in (1, 2, 5):
+        ok, ocn = oc.retain(cutoff)
+        assert g.retain(cutoff) == len(ok)
+        gk, gc = g.fetch_retained()
+        assert np.array_equal(gk, ok)          # same keys in the same (ascending) order
+        assert np.array_equal(gc, ocn)
+
+
+def test_ragged_reads_empty_reads_and_n_runs(gpu, oracle_built):
+    rng = np.random.default_rng(7)
+    lens = np.concatenate([[0, 1, 31, 32, 33, 0, 64, 499, 32, 0, 150, 151], rng.integers(0, 300, 2000)]).astype(np.uint64)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    codes = rng.integers(0, 4, int(off[-1])).astype(np.uint8)
+    codes[rng.random(codes.size) < 0.01] = 4
+    codes[off[7] + 100:off[7] + 140] = 4
+    for k in (32, 45):
+        oc = _oracle(codes, off, k, oracle_built)
+        ohist, omax = oc.occ_hist()
+        g = gpu(0)
+        # ragged appends of 1, 2, 3 ... reads so that every word alignment of an append boundary occurs
+        i, step = 0, 1
+        while i < len(lens):
+            j = min(i + step, len(lens))
+            g.reads_append(codes, off[i:j + 1])
+            i, step = j, step + 1
+        hist = g.make_kmer_read_distribution(k)
+        assert np.array_equal(hist, ohist) and g.max_occ == omax
+        ok, ocn = oc.retain(1)
+        g.retain(1)
+        gk, gc = g.fetch_retained()
+        assert np.array_equal(gk, ok) and np.array_equal(gc, ocn)
+        assert np.array_equal(g.length_hist(600), oc.length_hist(600))
+
+
+def test_ascii_input_uses_reference_char_table(gpu, oracle_built):
+    """common.h:256: upper and lower case, N/n -> unknown."""
+    reads = [b"ACGTacgtNNACGTTGCAtgcatgcaACGTACGTACGTACGTACGTnACGTTTGACCAGTCAGGCATTACGGATCAAAA", b"acgtacgtacgtacgtacgtacgtacgtacgtacgt"]
+    asc = np.frombuffer(b"".join(reads), dtype=np.uint8)
+    off = np.array([0, len(reads[0]), len(reads[0]) + len(reads[1])], dtype=np.uint64)
+    lut = np.full(256, 4, dtype=np.uint8)
+    for c, v in zip(b"ACGTacgt", [0, 1, 2, 3, 0, 1, 2, 3]):
+        lut[c] = v
+    codes = lut[asc]
+    oc = _oracle(codes, off, 21, oracle_built)
+    g = gpu(0)
+    g.reads_append(asc, off, ascii=True)
+    hist = g.make_kmer_read_distribution(21)
+    ohist, _ = oc.occ_hist()
+    assert np.array_equal(hist, ohist)
+    ok, ocn = oc.retain(1)
+    g.retain(1)
+    gk, gc = g.fetch_retained()
+    assert np.array_equal(gk, ok) and np.array_equal(gc, ocn)
+
+
+def test_saturation_at_65534(gpu):
+    """counter.h:468-470: counts stop at UINT16_MAX-1; 70000 copies of one read."""
+    read = np.array([0, 1, 2, 3] * 8 + [2, 2, 1], dtype=np.uint8)       # 35 bases -> 4 windows of 32
+    n = 70000
+    codes = np.tile(read, n)
+    g = gpu(0)
+    g.reads_append(codes, np.arange(n + 1, dtype=np.uint64) * np.uint64(len(read)))
+    hist = g.make_kmer_read_distribution(32)
+    assert g.max_occ == 65534
+    assert int(hist[65534]) == g.n_distinct
+    g.retain(1)
+    _, gc = g.fetch_retained()
+    assert (gc == 65534).all()
+
+
+def test_histogram_matches_reference_golden_tsv(gpu, manifest, tmp_path):
+    """PREFIX_32merFrq.tsv byte-identical to the file the real reference wrote (tests/golden)."""
+    for name, run, k in (("c1", "occ", 32), ("g5k", "k21_s0", 21), ("k45", "multik_k45", 45), ("c2", "multik_n2", 32)):
+        codes, off = case_reads(manifest[name])
+        g = gpu(0)
+        g.reads_append_matrix(codes)
+        g.make_kmer_read_distribution(k)
+        out = tmp_path / f"{name}_{k}merFrq.tsv"
+        g.output_occurrence_distribution(str(out))
+        gold = os.path.join(GOLDEN, f"{name}.{run}.out_{k}merFrq.tsv")
+        assert open(out, "rb").read() == open(gold, "rb").read()
+
+
+def test_full_size_properties(gpu):
+    """BASELINE config 2 shape at a size the oracle cannot finish in seconds (1 Mbp x 100x): size-independent
+    properties -- sum(hist) = distinct, sum(i*hist) = windows, retained keys strictly ascending, counting twice
+    gives the same table (idempotence), and read order does not matter (counts are commutative)."""
+    from platanus_b_amd import synth
+    r1, r2 = synth.make_reads(1_000_000, 100, seed=5)
+    g = gpu(0)
+    g.reads_append_matrix(r1)
+    g.reads_append_matrix(r2)
+    h1 = g.make_kmer_read_distribution(32).copy()
+    n_reads, n_bases = g.reads_info()
+    assert g.n_instances == n_reads * (150 - 32 + 1)
+    assert int(h1.sum()) == g.n_distinct
+    assert int((np.arange(65535, dtype=np.uint64) * h1).sum()) == g.n_instances
+    g.retain(3)
+    k1, c1 = g.fetch_retained()
+    assert (k1[1:, 0] > k1[:-1, 0]).all()
+    assert (c1 >= 3).all()
+    h2 = g.make_kmer_read_distribution(32)
+    assert np.array_equal(h1, h2)
+    g2 = gpu(0)
+    g2.reads_append_matrix(r2[::-1])
+    g2.reads_append_matrix(r1[::-1])
+    h3 = g2.make_kmer_read_distribution(32)
+    assert np.array_equal(h1, h3)
+    g2.retain(3)
+    k3, c3 = g2.fetch_retained()
+    assert np.array_equal(k1, k3) and np.array_equal(c1, c3)
+
+
+@pytest.mark.parametrize("k", [32, 45])
+def test_export_buckets_and_merge_roundtrip(k, gpu, oracle_built):
+    """X1 on one GPU: bucket the table into 8 owner parts, check every record sits in its owner's bucket, merge the
+    parts back (twice: counts double, saturating) and compare with the oracle."""
+    import ctypes as C
+    import torch
+    from platanus_b_amd import synth
+    from platanus_b_amd.multigpu import owner_of
+    r1, r2 = synth.make_reads(30_000, 40, seed=3, n_rate=0.001)
+    codes = np.concatenate([r1, r2])
+    n, L = codes.shape
+    off = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
+    oc = _oracle(codes, off, k, oracle_built)
+    ok, ocn = oc.retain(1)
+    W = (k + 31) // 32
+    g = gpu(0)
+    g.reads_append_matrix(codes)
+    g.make_kmer_read_distribution(k)
+    parts = (C.c_uint64 * 8)()
+    g._chk(g.lib.pb_export_begin(g.h, 8, parts))
+    send = [int(x) for x in parts]
+    assert sum(send) == len(ok)
+    tk = torch.empty(sum(send) * W, dtype=torch.int64, device="cuda")
+    tc = torch.empty(sum(send), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    g._chk(g.lib.pb_export_copy(g.h, C.c_void_p(tk.data_ptr()), C.c_void_p(tc.data_ptr())))
+    keys = tk.cpu().numpy().view(np.uint64).reshape(-1, W)
+    own = owner_of(keys[:, 0], 8)
+    bounds = np.concatenate([[0], np.cumsum(send)])
+    for r in range(8):
+        assert (own[bounds[r]:bounds[r + 1]] == r).all()
+    g._chk(g.lib.pb_merge_begin(g.h, k, sum(send)))
+    for _ in range(2):
+        g._chk(g.lib.pb_merge_add(g.h, C.c_void_p(tk.data_ptr()), C.c_void_p(tc.data_ptr()), sum(send)))
+    hist = np.zeros(65535, dtype=np.uint64)
+    mx, nd = C.c_uint64(), C.c_uint64()
+    g._chk(g.lib.pb_merge_end(g.h, hist.ctypes.data, C.byref(mx), C.byref(nd)))
+    assert nd.value == len(ok)
+    g.retain(1)
+    gk, gc = g.fetch_retained()
+    assert np.array_equal(gk, ok)
+    assert np.array_equal(gc, np.minimum(ocn.astype(np.int64) * 2, 65534).astype(np.uint16))
