@@ -38,20 +38,21 @@ BYTES_PER_INSTANCE = 0.25 + 8 * ((K + 31) // 32) + 4        # 12
 HBM_PEAK_GBS = 8000.0                                        # MI355X_MICROARCH.md: 8 TB/s spec
 
 
-def cpu_baseline(sample_genome=1_000_000, threads=None):
+def cpu_baseline(sample_cov=20.0, threads=None):
     """Counting-stage rate of the CPU reference on a bounded sample of the same workload (rank 0, N=1 only)."""
     from platanus_b_amd import synth
     from oracle import pyoracle
     ncpu = os.cpu_count() or 1
     threads = threads or min(8, ncpu)
-    n_pairs = int(sample_genome * COVERAGE) // (2 * READ_LEN)
+    # same genome as the GPU workload (same table pressure from genomic k-mers), one fifth of its coverage
+    n_pairs = int(GENOME * sample_cov) // (2 * READ_LEN)
     instances = 2 * n_pairs * (READ_LEN - K + 1)
-    sample = f"{sample_genome // 1000} kbp x {COVERAGE:.0f}x PE{READ_LEN} seed {SEED} ({2 * n_pairs} reads, {instances} {K}-mers), counting stage only"
+    sample = f"{GENOME / 1e6:g} Mbp x {sample_cov:.0f}x PE{READ_LEN} seed {SEED} ({2 * n_pairs} reads, {instances} {K}-mers), counting stage only"
     if pyoracle.have_reference():
         tmp = tempfile.mkdtemp(prefix="pb_cpu_")
         try:
-            synth.write_pair_files(os.path.join(tmp, "s"), sample_genome, COVERAGE, SEED)
-            cmd = [pyoracle.REF_BIN, "assemble", "-k", str(K), "-t", str(threads), "-m", "4", "-kmer_occ_only", "-tmp", tmp,
+            synth.write_pair_files(os.path.join(tmp, "s"), GENOME, sample_cov, SEED)
+            cmd = [pyoracle.REF_BIN, "assemble", "-k", str(K), "-t", str(threads), "-m", "16", "-kmer_occ_only", "-tmp", tmp,
                    "-o", os.path.join(tmp, "o"), "-f", os.path.join(tmp, "s_1.fq"), os.path.join(tmp, "s_2.fq")]
             p = subprocess.Popen(cmd, stderr=subprocess.PIPE, stdout=subprocess.DEVNULL, text=True)
             t0 = t1 = None
@@ -65,11 +66,11 @@ def cpu_baseline(sample_genome=1_000_000, threads=None):
             p.wait()
             if t0 is not None and t1 is not None:
                 return {"value": instances / (t1 - t0), "unit": "k-mers/s", "cores": threads, "kind": "reference",
-                        "sample": sample + f", -t {threads} -m 4, {t1 - t0:.1f} s"}
+                        "sample": sample + f", -t {threads} -m 16 (reference defaults), {t1 - t0:.1f} s"}
         finally:
             subprocess.run(["rm", "-rf", tmp])
     # CPU port (oracle restatement, single thread)
-    r1, r2 = synth.make_reads(sample_genome // 4, COVERAGE, SEED)
+    r1, r2 = synth.make_reads(GENOME, sample_cov / 4, SEED)
     codes = np.concatenate([r1, r2])
     n, L = codes.shape
     oc = pyoracle.OracleCounter()
@@ -77,7 +78,7 @@ def cpu_baseline(sample_genome=1_000_000, threads=None):
     oc.count(codes.reshape(-1), np.arange(n + 1, dtype=np.uint64) * np.uint64(L), K, 4 * 10 ** 9)
     dt = time.perf_counter() - t0
     return {"value": n * (L - K + 1) / dt, "unit": "k-mers/s", "cores": 1, "kind": "port",
-            "sample": f"{sample_genome // 4000} kbp x {COVERAGE:.0f}x PE{READ_LEN} seed {SEED}, oracle/ restatement -t 1, {dt:.1f} s"}
+            "sample": f"{GENOME / 1e6:g} Mbp x {sample_cov / 4:.0f}x PE{READ_LEN} seed {SEED}, oracle/ restatement -t 1, {dt:.1f} s"}
 
 
 def main():

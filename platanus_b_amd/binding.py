@@ -36,6 +36,14 @@ def load_library() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise FileNotFoundError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    # torch's ROCm wheel bundles its own libamdhip64.so.7 / libhsa-runtime64; whichever HIP runtime is loaded
+    # first serves the whole process.  Loading libpbgpu first and torch afterwards leaves torch without a
+    # device ("No HIP GPUs are available", measured), so when torch is installed it goes first and both share
+    # one runtime -- torch tensors' device pointers are then valid in libpbgpu and vice versa.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     vp, u64p = C.c_void_p, C.POINTER(C.c_uint64)
     lib.pb_create.argtypes = [C.c_int, C.POINTER(vp)]

@@ -38,7 +38,8 @@ def test_count_matches_oracle_all_key_widths(k, gpu, oracle_built):
     assert np.array_equal(hist, ohist)
     assert g.max_occ == omax
     assert g.n_distinct == int(ohist.sum())
-    assert g.n_instances == int((np.arange(65535, dtype=np.uint64) * ohist).sum())
+    if omax < 65534:                    # below saturation sum(i * hist[i]) is the number of windows
+        assert g.n_instances == int((np.arange(65535, dtype=np.uint64) * ohist).sum())
     assert np.array_equal(g.length_hist(200), oc.length_hist(200))
     for cutoff in (1, 2, 5):
         ok, ocn = oc.retain(cutoff)
