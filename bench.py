@@ -130,6 +130,7 @@ def main():
     for _ in range(a.warmup):
         step()
     count_ms, init_ms, hist_ms = [], [], []
+    stage_ms = {"part1": [], "part2": [], "bucket": [], "seg_compact": [], "compact": []}
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -139,6 +140,8 @@ def main():
         count_ms.append(g.kernel_ms("count"))
         init_ms.append(g.kernel_ms("table_init"))
         hist_ms.append(g.kernel_ms("hist"))
+        for st in stage_ms:
+            stage_ms[st].append(g.kernel_ms(st))
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -155,20 +158,29 @@ def main():
         total_instances = instances
 
     if rank == 0:
-        k_ms = float(np.mean(count_ms))
+        k_ms = float(np.mean(count_ms))        # all kernels of the counting pass (HIP events on the library's stream)
         achieved = instances * BYTES_PER_INSTANCE / (k_ms * 1e-3) / 1e9
+        parts = {st: float(np.mean(v)) for st, v in stage_ms.items()}
+        partitioned = parts["part1"] > 0
+        kernel = ("part1_kernel + part2_kernel + bucket_count_kernel + bucket_compact_kernel (partitioned counting pass)"
+                  if partitioned else "count_kernel<1> (direct global-atomic counting pass)")
+        traffic = None
+        if os.environ.get("PB_HBM_TRAFFIC_BYTES"):       # measured with rocprofv3 --pmc in a separate run (profiles/)
+            traffic = float(os.environ["PB_HBM_TRAFFIC_BYTES"])
         out = {
             "metric": "k-mers/sec", "value": total_instances * a.steps / dt, "unit": "k-mers/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"{a.genome / 1e6:g} Mbp synthetic genome, {COVERAGE * world:.0f}x PE{READ_LEN}, k={K}, "
                                    f"occurrence table only (BASELINE configs[1] per GPU)",
-                       "reads_per_gpu": int(n_reads), "kmer_instances_per_gpu": int(instances), "distinct_kmers_rank0": int(g.n_distinct),
+                       "reads_per_gpu": int(n_reads), "kmer_instances_per_gpu": int(instances), "distinct_kmers": int(g.n_distinct),
                        "parallelism": f"reads range-partitioned over {world} GPU(s)" + (", owner exchange over RCCL" if world > 1 else "")},
-            "roofline": {"bound": "hbm", "kernel": "count_kernel<1>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": k_ms,
+            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": instances * BYTES_PER_INSTANCE,
-                         "other_kernels_ms": {"table_init": float(np.mean(init_ms)), "hist": float(np.mean(hist_ms))}},
+                         "kernels_ms": {"part1": parts["part1"], "part2": parts["part2"], "bucket_count": parts["bucket"],
+                                        "bucket_compact": parts["seg_compact"], "table_init": float(np.mean(init_ms)),
+                                        "table_to_arrays": parts["compact"], "hist": float(np.mean(hist_ms))}},
         }
         if world == 1 and not a.no_cpu_baseline:
             try:

@@ -51,14 +51,21 @@ struct pb_ctx {
     DevBuf ret_keys, ret_counts;        // u64[n*W], u16[n]
     u64 n_retained = 0;
 
+    // distinct (key,count) arrays of the last pb_count / pb_merge_end (device form of kmerFP)
+    DevBuf dist_keys, dist_counts;      // u64[n*W], u32[n]
+    int count_path = 0;                 // 1 = direct (v1), 2 = partitioned (v2)
+    DevBuf part_bucket1, part_bucket2, part_meta, part_out_counts, part_segs;
+
     // owner exchange (X1)
     DevBuf exp_keys, exp_counts, merge_table;
-    u64 exp_total = 0, merge_cap = 0;
+    u64 exp_total = 0, merge_cap = 0, merge_records = 0;
     unsigned exp_parts = 0;
 
     // scratch
     DevBuf scratch[6];
 };
+
+#define PB_STREAM_PAD_WORDS64 8      /* 512 positions of padding: a 160-mer window never leaves the buffer */
 
 static std::string g_create_error;
 
@@ -228,46 +235,16 @@ __global__ void table_init_kernel(u64 *__restrict__ slots, u64 cap)
 }
 
 // ------------------------------------------------------------------------------------------------------
-// K4a: histogram of saturated counts.  Bins < 4096 live in LDS (16 KB), the rare larger counts go
-// straight to global memory.  hist[65535] is used as the "distinct keys" counter (bin 65535 is never a
-// count: saturation is at 65534, counter.h:468-470).
+// Result representation.  Whatever counting path ran, pb_count leaves the distinct k-mers as two device
+// arrays: dist_keys u64[n*W] and dist_counts u32[n] (unsorted).  That is the device form of the reference's
+// kmerFP temp file (counter.h:482-507); histogram, cutoff filter, sort and owner export all read it.
 // ------------------------------------------------------------------------------------------------------
-#define HIST_LDS_BINS 4096
-template <int W>
-__global__ void __launch_bounds__(256)
-hist_kernel(TableView<W> table, u64 *__restrict__ hist)
-{
-    __shared__ u32 lh[HIST_LDS_BINS];
-    for (unsigned i = threadIdx.x; i < HIST_LDS_BINS; i += blockDim.x) lh[i] = 0;
-    __syncthreads();
-    const u64 cap = table.mask + 1;
-    const u64 stride = (u64)gridDim.x * blockDim.x;
-    u64 distinct = 0;
-    for (u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x; s < cap; s += stride) {
-        const u64 *slot = table.slots + s * PB_SLOT_WORDS(W);
-        bool occ;
-        u32 c;
-        if (W == 1) { occ = slot[0] != PB_EMPTY_KEY; c = (u32)slot[1]; }
-        else { const u64 meta = slot[W]; occ = (meta >> 32) != 0; c = (u32)meta; }
-        if (!occ || c == 0) continue;
-        if (c > PB_COUNT_MAX) c = PB_COUNT_MAX;
-        ++distinct;
-        if (c < HIST_LDS_BINS) atomicAdd(&lh[c], 1u);
-        else atomicAdd(&hist[c], 1ull);
-    }
-    for (int o = 32; o > 0; o >>= 1) distinct += __shfl_down(distinct, o, 64);
-    if ((threadIdx.x & 63) == 0 && distinct) atomicAdd(&hist[65535], distinct);
-    __syncthreads();
-    for (unsigned i = threadIdx.x; i < HIST_LDS_BINS; i += blockDim.x)
-        if (lh[i]) atomicAdd(&hist[i], (u64)lh[i]);
-}
 
-// K4b: stream compaction of slots with min_occ <= count.  Output order is arbitrary (the sort follows).
-// One atomic per wave: lanes are ranked with __ballot + popcount.
+// table -> arrays.  One atomic per wave: lanes are ranked with __ballot + popcount.
 template <int W>
 __global__ void __launch_bounds__(256)
-compact_kernel(TableView<W> table, u32 min_occ, u64 *__restrict__ out_keys, u32 *__restrict__ out_counts,
-               u64 cap_out, u64 *__restrict__ counter)
+table_to_arrays_kernel(TableView<W> table, u64 *__restrict__ out_keys, u32 *__restrict__ out_counts, u64 cap_out,
+                       u64 *__restrict__ counter)
 {
     const u64 cap = table.mask + 1;
     const u64 stride = (u64)gridDim.x * blockDim.x;
@@ -283,8 +260,7 @@ compact_kernel(TableView<W> table, u32 min_occ, u64 *__restrict__ out_keys, u32 
             bool occ;
             if (W == 1) { occ = slot[0] != PB_EMPTY_KEY; c = (u32)slot[1]; }
             else { const u64 meta = slot[W]; occ = (meta >> 32) != 0; c = (u32)meta; }
-            if (c > PB_COUNT_MAX) c = PB_COUNT_MAX;
-            take = occ && c != 0 && c >= min_occ;
+            take = occ && c != 0;
         }
         const u64 ballot = __ballot(take);
         if (ballot == 0) continue;
@@ -303,6 +279,54 @@ compact_kernel(TableView<W> table, u32 min_occ, u64 *__restrict__ out_keys, u32 
     }
 }
 
+// K4a: occurrenceDistribution (counter.h:482-507) from the count array.  Bins < 4096 live in LDS (16 KB),
+// the rare larger counts go straight to global memory.
+#define HIST_LDS_BINS 4096
+__global__ void __launch_bounds__(256)
+hist_array_kernel(const u32 *__restrict__ counts, u64 n, u64 *__restrict__ hist)
+{
+    __shared__ u32 lh[HIST_LDS_BINS];
+    for (unsigned i = threadIdx.x; i < HIST_LDS_BINS; i += blockDim.x) lh[i] = 0;
+    __syncthreads();
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        u32 c = counts[i];
+        if (c == 0) continue;
+        if (c > PB_COUNT_MAX) c = PB_COUNT_MAX;
+        if (c < HIST_LDS_BINS) atomicAdd(&lh[c], 1u);
+        else atomicAdd(&hist[c], 1ull);
+    }
+    __syncthreads();
+    for (unsigned i = threadIdx.x; i < HIST_LDS_BINS; i += blockDim.x)
+        if (lh[i]) atomicAdd(&hist[i], (u64)lh[i]);
+}
+
+// K4b: keep records with min_occ <= min(count, 65534) (sortedKeyFromKmerFile's filter, counter.h:927-934)
+__global__ void __launch_bounds__(256)
+filter_array_kernel(const u64 *__restrict__ keys, const u32 *__restrict__ counts, u64 n, int W, u32 min_occ,
+                    u64 *__restrict__ out_keys, u32 *__restrict__ out_counts, u64 *__restrict__ counter)
+{
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    const unsigned lane = threadIdx.x & 63;
+    const u64 n_iter = (n + stride - 1) / stride;
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (u64 it = 0; it < n_iter; ++it, i += stride) {
+        u32 c = i < n ? counts[i] : 0;
+        if (c > PB_COUNT_MAX) c = PB_COUNT_MAX;
+        const bool take = c != 0 && c >= min_occ;
+        const u64 ballot = __ballot(take);
+        if (ballot == 0) continue;
+        u64 base = 0;
+        const int leader = __ffsll((long long)ballot) - 1;
+        if ((int)lane == leader) base = atomicAdd(counter, (u64)__popcll(ballot));
+        base = __shfl(base, leader, 64);
+        if (take) {
+            const u64 pos = base + __popcll(ballot & ((1ull << lane) - 1));
+            for (int w = 0; w < W; ++w) out_keys[pos * W + w] = keys[i * W + w];
+            out_counts[pos] = c;
+        }
+    }
+}
 
 // ------------------------------------------------------------------------------------------------------
 // X1 (no reference counterpart: the reference's threads share one table).  Multi-GPU merge of per-GPU
@@ -314,57 +338,46 @@ compact_kernel(TableView<W> table, u32 min_occ, u64 *__restrict__ out_keys, u32 
 //                         read-out (counter.h:468-470), so the union of owner shards is the -t 1 table
 // ------------------------------------------------------------------------------------------------------
 #define PB_MAX_PARTS 64
-template <int W>
-__device__ __forceinline__ bool slot_record(const TableView<W> &t, u64 s, u32 &c, const u64 *&slot)
-{
-    slot = t.slots + s * PB_SLOT_WORDS(W);
-    bool occ;
-    if (W == 1) { occ = slot[0] != PB_EMPTY_KEY; c = (u32)slot[1]; }
-    else { const u64 meta = slot[W]; occ = (meta >> 32) != 0; c = (u32)meta; }
-    return occ && c != 0;
-}
-
-template <int W>
 __global__ void __launch_bounds__(256)
-part_count_kernel(TableView<W> table, unsigned n_parts, u64 *__restrict__ part_counts)
+part_count_kernel(const u64 *__restrict__ keys, const u32 *__restrict__ counts, u64 n, int W, unsigned n_parts,
+                  u64 *__restrict__ part_counts)
 {
     __shared__ u32 lc[PB_MAX_PARTS];
     if (threadIdx.x < PB_MAX_PARTS) lc[threadIdx.x] = 0;
     __syncthreads();
-    const u64 cap = table.mask + 1, stride = (u64)gridDim.x * blockDim.x;
-    for (u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x; s < cap; s += stride) {
-        u32 c; const u64 *slot;
-        if (!slot_record<W>(table, s, c, slot)) continue;
-        atomicAdd(&lc[(unsigned)(((slot[0] & 1023) * n_parts) >> 10)], 1u);
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if (counts[i] == 0) continue;
+        atomicAdd(&lc[(unsigned)(((keys[i * W] & 1023) * n_parts) >> 10)], 1u);
     }
     __syncthreads();
     if (threadIdx.x < n_parts && lc[threadIdx.x]) atomicAdd(&part_counts[threadIdx.x], (u64)lc[threadIdx.x]);
 }
 
-template <int W>
 __global__ void __launch_bounds__(256)
-part_scatter_kernel(TableView<W> table, unsigned n_parts, u64 *__restrict__ cursors /* start offsets, advanced */,
-                    u64 *__restrict__ out_keys, u32 *__restrict__ out_counts)
+part_scatter_kernel(const u64 *__restrict__ keys, const u32 *__restrict__ counts, u64 n, int W, unsigned n_parts,
+                    u64 *__restrict__ cursors /* start offsets, advanced */, u64 *__restrict__ out_keys,
+                    u32 *__restrict__ out_counts)
 {
     __shared__ u32 lc[PB_MAX_PARTS];
     __shared__ u64 lbase[PB_MAX_PARTS];
-    const u64 cap = table.mask + 1, stride = (u64)gridDim.x * blockDim.x;
-    const u64 n_iter = (cap + stride - 1) / stride;
-    u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    for (u64 it = 0; it < n_iter; ++it, s += stride) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    const u64 n_iter = (n + stride - 1) / stride;
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (u64 it = 0; it < n_iter; ++it, i += stride) {
         if (threadIdx.x < PB_MAX_PARTS) lc[threadIdx.x] = 0;
         __syncthreads();
-        u32 c = 0; const u64 *slot = nullptr;
-        const bool take = s < cap && slot_record<W>(table, s, c, slot);
-        unsigned owner = 0; u32 local = 0;
-        if (take) { owner = (unsigned)(((slot[0] & 1023) * n_parts) >> 10); local = atomicAdd(&lc[owner], 1u); }
+        const u32 c = i < n ? counts[i] : 0;
+        const bool take = c != 0;
+        unsigned owner = 0;
+        u32 local = 0;
+        if (take) { owner = (unsigned)(((keys[i * W] & 1023) * n_parts) >> 10); local = atomicAdd(&lc[owner], 1u); }
         __syncthreads();
         if (threadIdx.x < n_parts && lc[threadIdx.x]) lbase[threadIdx.x] = atomicAdd(&cursors[threadIdx.x], (u64)lc[threadIdx.x]);
         __syncthreads();
         if (take) {
             const u64 pos = lbase[owner] + local;
-#pragma unroll
-            for (int i = 0; i < W; ++i) out_keys[pos * W + i] = slot[i];
+            for (int w = 0; w < W; ++w) out_keys[pos * W + w] = keys[i * W + w];
             out_counts[pos] = c > PB_COUNT_MAX ? PB_COUNT_MAX : c;
         }
         __syncthreads();
@@ -385,6 +398,363 @@ merge_kernel(const u64 *__restrict__ keys, const u32 *__restrict__ counts, u64 n
         if (!table_add<W>(table, key, counts[i], max_probe)) ovf = true;
     }
     if (ovf) scalars[1] = 1;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K2+K3, partitioned form (k <= 32).  The v1 kernel above does two random device-scope atomics per window on
+// a multi-GB table and is bound by the atomic units (measured 18 ms for cfg2).  Here the random access is
+// moved into LDS:
+//   part1_kernel  extract canonical k-mers from the packed stream and scatter them by hash digit 1 into
+//                 2^l1 level-1 buckets.  A block stages a tile of keys in LDS sorted by digit (LDS counting
+//                 sort), reserves one range per digit with a single global atomic, and copies every run with
+//                 coalesced stores.
+//   part2_kernel  same on each level-1 bucket with hash digit 2 -> 2^(l1+l2) final buckets of <= PB_BUCKET_CAP
+//                 keys (mean <= 1536: hash partitioning makes sizes Poisson, capacity = mean + 13 sigma).
+//   bucket_count_kernel  one block per final bucket: open-addressing occurrence hashing in LDS (64-bit LDS CAS on
+//                 the key claims a slot, 32-bit LDS add counts), then the (key,count) records of the bucket are
+//                 appended to the distinct arrays with one global atomic per block.
+// A bucket that overflows its capacity (one k-mer with an enormous count, or a level-1 overflow) is flagged;
+// everything of a flagged bucket is counted through the v1 global table instead (fallback, always correct).
+// ------------------------------------------------------------------------------------------------------
+#define PB_TILE 8192                 /* keys staged per block iteration: 64 KB of LDS                    */
+#define PB_PART_THREADS 1024         /* one 1024-lane block per CU (tile staging takes ~95 KB of its LDS): 16 waves */
+#define PB_TILE_ITEMS (PB_TILE / PB_PART_THREADS)
+#define PB_MAX_DIGITS 1024
+#define PB_BUCKET_CAP 2048           /* keys per final bucket                                             */
+#define PB_BUCKET_SLOTS 4096         /* LDS table slots per final bucket: load <= 0.5 even if all distinct */
+
+struct PartParams {
+    unsigned l1, l2;                 // digit widths: level-1 buckets = 2^l1, final buckets = 2^(l1+l2)
+    u64 cap1;                        // capacity (keys) of a level-1 sub-stream (bucket x XCD)
+    u64 *bucket1;                    // [2^l1 * PB_XCD * cap1]
+    u32 *cursor1;                    // [2^l1 * PB_XCD] keys appended so far (may exceed cap1: the excess went to the fallback)
+    u64 *bucket2;                    // [2^(l1+l2) * PB_BUCKET_CAP]
+    u32 *cursor2;                    // [2^(l1+l2)]
+    u32 *flag2;                      // [2^(l1+l2)] 1 = some key of this final bucket went to the fallback table
+    TableView<1> fallback;
+    u64 *scalars;                    // [0] instances [1] fallback overflow
+};
+
+__device__ __forceinline__ u64 part_hash(u64 key) { return mix64(key); }
+
+// Scatter `nvalid` keys held in registers (kreg[j], valid bit j of vmask) into 2^bits destinations.
+// digit(key) = (part_hash(key) >> shift) & (2^bits - 1).  dst_of(d) gives base pointer, capacity and cursor.
+template <typename DST>
+__device__ __forceinline__ void tile_scatter(const u64 (&kreg)[PB_TILE_ITEMS], u32 vmask, unsigned shift, unsigned bits, DST dst,
+                                             u64 *skeys, u16 *sdig, u32 *shist, u32 *soff, u32 *sbase)
+{
+    const unsigned nd = 1u << bits;
+    if (threadIdx.x < nd) shist[threadIdx.x] = 0;
+    __syncthreads();
+    u16 dreg[PB_TILE_ITEMS];
+#pragma unroll
+    for (int j = 0; j < PB_TILE_ITEMS; ++j) {
+        dreg[j] = (u16)((unsigned)(part_hash(kreg[j]) >> shift) & (nd - 1));
+        if (vmask & (1u << j)) atomicAdd(&shist[dreg[j]], 1u);
+    }
+    __syncthreads();
+    // exclusive scan of shist[0..nd) -> soff (nd <= 1024 = one bin per lane: wave scan + 16 wave totals)
+    {
+        __shared__ u32 wtot[PB_PART_THREADS / 64];
+        const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const u32 v = threadIdx.x < nd ? shist[threadIdx.x] : 0;
+        u32 x = v;
+        for (int o = 1; o < 64; o <<= 1) { const u32 y = __shfl_up(x, o, 64); if ((int)lane >= o) x += y; }
+        if (lane == 63) wtot[wave] = x;
+        __syncthreads();
+        u32 run = x - v;
+        for (unsigned w = 0; w < wave; ++w) run += wtot[w];
+        if (threadIdx.x < nd) { soff[threadIdx.x] = run; sbase[threadIdx.x] = run; }
+    }
+    __syncthreads();
+    // place keys (sbase doubles as the running LDS cursor)
+#pragma unroll
+    for (int j = 0; j < PB_TILE_ITEMS; ++j)
+        if (vmask & (1u << j)) {
+            const u32 pos = atomicAdd(&sbase[dreg[j]], 1u);
+            skeys[pos] = kreg[j];
+            sdig[pos] = dreg[j];
+        }
+    __syncthreads();
+    // reserve one global range per non-empty digit
+    if (threadIdx.x < nd) {
+        const u32 cnt = shist[threadIdx.x];
+        sbase[threadIdx.x] = cnt ? dst.reserve(threadIdx.x, cnt) : 0;
+    }
+    __syncthreads();
+    const u32 total = soff[nd - 1] + shist[nd - 1];
+    for (u32 i = threadIdx.x; i < total; i += PB_PART_THREADS) {
+        const unsigned d = sdig[i];
+        dst.store(d, sbase[d] + (i - soff[d]), skeys[i]);
+    }
+    __syncthreads();
+}
+
+// Level-1 buckets are split into PB_XCD sub-streams, one per XCD: a block appends to the sub-stream of the XCD it
+// runs on (HW_REG_XCC_ID; speed only -- any value is correct).  Appends to one sub-stream then all come through the
+// same L2, whose write-back merges the ~100-byte runs of different blocks into full lines before they reach HBM;
+// with one shared stream per bucket the eight non-coherent L2s each write partial lines of the same bucket tail
+// (measured: part1 6.1 ms for 3.2 GB of keys against part2's 1.9 ms for the same bytes).
+#define PB_XCD 8
+__device__ __forceinline__ unsigned xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | 20) & (PB_XCD - 1); }   // HW_REG_XCC_ID[3:0]
+
+struct Dst1 {
+    PartParams p;
+    unsigned x;
+    __device__ __forceinline__ u32 reserve(unsigned d, u32 cnt) const { return atomicAdd(&p.cursor1[d * PB_XCD + x], cnt); }
+    __device__ __forceinline__ void store(unsigned d, u32 pos, u64 key) const
+    {
+        if (pos < p.cap1) p.bucket1[((u64)d * PB_XCD + x) * p.cap1 + pos] = key;
+        else {   // level-1 overflow: the key is counted in the fallback table and its final bucket is flagged
+            p.flag2[(unsigned)(part_hash(key) >> (64 - p.l1 - p.l2))] = 1;
+            DKey<1> k1; k1.w[0] = key;
+            if (!table_add<1>(p.fallback, k1, 1u, 1024u)) p.scalars[1] = 1;
+        }
+    }
+};
+struct Dst2 {
+    PartParams p;
+    unsigned b1;
+    __device__ __forceinline__ u32 reserve(unsigned d, u32 cnt) const { return atomicAdd(&p.cursor2[(b1 << p.l2) + d], cnt); }
+    __device__ __forceinline__ void store(unsigned d, u32 pos, u64 key) const
+    {
+        const unsigned b = (b1 << p.l2) + d;
+        if (pos < PB_BUCKET_CAP) p.bucket2[(u64)b * PB_BUCKET_CAP + pos] = key;
+        else {
+            p.flag2[b] = 1;
+            DKey<1> k1; k1.w[0] = key;
+            if (!table_add<1>(p.fallback, k1, 1u, 1024u)) p.scalars[1] = 1;
+        }
+    }
+};
+
+// k <= 32 window test on LDS-staged mask words: bits [g, g+k) of the mask stream
+__device__ __forceinline__ bool lds_window_has_n(const u64 *__restrict__ sm, u32 rel, unsigned k)
+{
+    const u32 wi = rel >> 6, sh = rel & 63;
+    const u64 lo = sm[wi] >> sh;
+    const u64 hi = sh ? (sm[wi + 1] << (64 - sh)) : 0;
+    const u64 m = k == 64 ? ~0ull : ((1ull << k) - 1);
+    return ((lo | hi) & m) != 0;
+}
+__device__ __forceinline__ u64 lds_kmer(const u64 *__restrict__ sp, u32 rel, unsigned k)
+{
+    const u32 bit = 2 * rel, wi = bit >> 6, sh = bit & 63;
+    const u64 hi = sp[wi];
+    const u64 v = sh ? ((hi << sh) | (sp[wi + 1] >> (64 - sh))) : hi;
+    return v >> (64 - 2 * k);
+}
+
+#define PB_TILE_PWORDS (PB_TILE / 32 + 2)      /* packed words covering a tile + one k-mer of overhang */
+#define PB_TILE_MWORDS (PB_TILE / 64 + 2)
+
+__global__ void __launch_bounds__(PB_PART_THREADS)
+part1_kernel(const u64 *__restrict__ packed, const u64 *__restrict__ nmask, u64 stream_len, u64 n_words64, unsigned k, PartParams p)
+{
+    __shared__ u64 skeys[PB_TILE];
+    __shared__ u16 sdig[PB_TILE];
+    __shared__ u32 shist[PB_MAX_DIGITS], soff[PB_MAX_DIGITS], sbase[PB_MAX_DIGITS];
+    __shared__ u64 spack[PB_TILE_PWORDS], smask[PB_TILE_MWORDS];
+    const u64 n_tiles = (stream_len + PB_TILE - 1) / PB_TILE;
+    const unsigned xcd = xcc_id();
+    u64 local = 0;
+    for (u64 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const u64 g0 = tile * PB_TILE;                       // multiple of 64: word aligned in both streams
+        // words past the allocation (last tile) read as all-unknown
+        for (unsigned i = threadIdx.x; i < PB_TILE_PWORDS; i += PB_PART_THREADS) spack[i] = g0 / 32 + i < 2 * n_words64 ? packed[g0 / 32 + i] : 0ull;
+        for (unsigned i = threadIdx.x; i < PB_TILE_MWORDS; i += PB_PART_THREADS) smask[i] = g0 / 64 + i < n_words64 ? nmask[g0 / 64 + i] : ~0ull;
+        __syncthreads();
+        u64 kreg[PB_TILE_ITEMS];
+        u32 vmask = 0;
+#pragma unroll
+        for (int j = 0; j < PB_TILE_ITEMS; ++j) {
+            const u32 rel = (u32)j * PB_PART_THREADS + threadIdx.x;
+            kreg[j] = 0;
+            if (g0 + rel + k <= stream_len && !lds_window_has_n(smask, rel, k)) {
+                DKey<1> f; f.w[0] = lds_kmer(spack, rel, k);
+                kreg[j] = key_canon<1>(f, k).w[0];
+                vmask |= 1u << j;
+            }
+        }
+        local += __popc(vmask);
+        tile_scatter(kreg, vmask, 64 - p.l1, p.l1, Dst1{p, xcd}, skeys, sdig, shist, soff, sbase);
+    }
+    for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o, 64);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(&p.scalars[0], local);
+}
+
+// grid = (tiles per level-1 sub-stream, 2^l1 * PB_XCD)
+__global__ void __launch_bounds__(PB_PART_THREADS)
+part2_kernel(PartParams p)
+{
+    __shared__ u64 skeys[PB_TILE];
+    __shared__ u16 sdig[PB_TILE];
+    __shared__ u32 shist[PB_MAX_DIGITS], soff[PB_MAX_DIGITS], sbase[PB_MAX_DIGITS];
+    const unsigned sub = blockIdx.y;             // level-1 sub-stream = bucket * PB_XCD + xcd
+    const unsigned b1 = sub / PB_XCD;
+    u64 n = p.cursor1[sub];
+    if (n > p.cap1) n = p.cap1;
+    const u64 *src = p.bucket1 + (u64)sub * p.cap1;
+    for (u64 tile = blockIdx.x; tile * PB_TILE < n; tile += gridDim.x) {
+        u64 kreg[PB_TILE_ITEMS];
+        u32 vmask = 0;
+#pragma unroll
+        for (int j = 0; j < PB_TILE_ITEMS; ++j) {
+            const u64 i = tile * PB_TILE + (u64)j * PB_PART_THREADS + threadIdx.x;
+            kreg[j] = 0;
+            if (i < n) { kreg[j] = src[i]; vmask |= 1u << j; }
+        }
+        tile_scatter(kreg, vmask, 64 - p.l1 - p.l2, p.l2, Dst2{p, b1}, skeys, sdig, shist, soff, sbase);
+    }
+}
+
+// exclusive scan of min(in[i], clamp) over n <= 2^20 entries (n a multiple of 1024) into u64 out[]; total -> *total
+__global__ void __launch_bounds__(256)
+scan_local_kernel(const u32 *__restrict__ in, u32 clamp, u64 *__restrict__ out, u64 *__restrict__ block_sums)
+{
+    __shared__ u32 wtot[4];
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u64 i0 = (u64)blockIdx.x * 1024 + threadIdx.x * 4;
+    u32 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const u32 c = in[i0 + q]; v[q] = c > clamp ? clamp : c; }
+    const u32 sum4 = v[0] + v[1] + v[2] + v[3];
+    u32 x = sum4;
+    for (int o = 1; o < 64; o <<= 1) { const u32 y = __shfl_up(x, o, 64); if ((int)lane >= o) x += y; }
+    if (lane == 63) wtot[wave] = x;
+    __syncthreads();
+    u32 run = x - sum4;
+    for (unsigned w = 0; w < wave; ++w) run += wtot[w];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { out[i0 + q] = run; run += v[q]; }
+    if (threadIdx.x == 255) block_sums[blockIdx.x] = run;
+}
+__global__ void __launch_bounds__(1024)
+scan_sums_kernel(u64 *__restrict__ block_sums, unsigned n_blocks, u64 *__restrict__ total)
+{
+    __shared__ u64 wtot[16];
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u64 v = threadIdx.x < n_blocks ? block_sums[threadIdx.x] : 0;
+    u64 x = v;
+    for (int o = 1; o < 64; o <<= 1) { const u64 y = __shfl_up(x, o, 64); if ((int)lane >= o) x += y; }
+    if (lane == 63) wtot[wave] = x;
+    __syncthreads();
+    u64 run = x - v;
+    for (unsigned w = 0; w < wave; ++w) run += wtot[w];
+    if (threadIdx.x < n_blocks) block_sums[threadIdx.x] = run;
+    if (threadIdx.x == n_blocks - 1) *total = run + v;
+}
+__global__ void __launch_bounds__(256)
+scan_add_kernel(u64 *__restrict__ out, const u64 *__restrict__ block_sums)
+{
+    const u64 i0 = (u64)blockIdx.x * 1024 + threadIdx.x * 4;
+    const u64 add = block_sums[blockIdx.x];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) out[i0 + q] += add;
+}
+
+// One block per final bucket: LDS-resident open-addressing occurrence hashing.  The bucket's records are written at
+// bucket_base[b] (exclusive prefix of the bucket sizes, an upper bound of the records before it), so no global
+// atomic is on the block's critical path; n_occ[b] records are valid, a later pass closes the gaps.
+__global__ void __launch_bounds__(256)
+bucket_count_kernel(PartParams p, u64 *__restrict__ out_keys, u32 *__restrict__ out_counts, const u64 *__restrict__ bucket_base,
+                    u32 *__restrict__ n_occ_out)
+{
+    __shared__ u64 lkeys[PB_BUCKET_SLOTS];
+    __shared__ u32 lcnt[PB_BUCKET_SLOTS];
+    __shared__ u32 wtot[4];
+    const unsigned n_buckets = 1u << (p.l1 + p.l2);
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int KPL = PB_BUCKET_CAP / 256;         // keys per lane
+    constexpr int SPL = PB_BUCKET_SLOTS / 256;       // table slots per lane (contiguous: lane t owns slots [t*SPL, (t+1)*SPL))
+
+    // software pipeline: the keys of the block's next bucket are loaded while the current one is emitted
+    u64 kin[KPL];
+    u32 n = 0;
+    bool flagged = false;
+    auto fetch = [&](unsigned b) {
+        n = 0; flagged = false;
+        if (b >= n_buckets) return;
+        n = p.cursor2[b];
+        if (n > PB_BUCKET_CAP) n = PB_BUCKET_CAP;
+        flagged = p.flag2[b] != 0;
+        const u64 *src = p.bucket2 + (u64)b * PB_BUCKET_CAP;
+#pragma unroll
+        for (int j = 0; j < KPL; ++j) {
+            const u32 i = (u32)j * 256 + threadIdx.x;
+            kin[j] = i < n ? src[i] : PB_EMPTY_KEY;
+        }
+    };
+    fetch(blockIdx.x);
+    for (unsigned b = blockIdx.x; b < n_buckets; b += gridDim.x) {
+        const u32 cur_n = n;
+        const bool cur_flagged = flagged;
+        if (cur_n == 0) { fetch(b + gridDim.x); continue; }          // n_occ_out[b] stays 0 (memset)
+        if (cur_flagged) {           // flagged: count through the global fallback table
+#pragma unroll
+            for (int j = 0; j < KPL; ++j)
+                if (kin[j] != PB_EMPTY_KEY) {
+                    DKey<1> k1; k1.w[0] = kin[j];
+                    if (!table_add<1>(p.fallback, k1, 1u, 1024u)) p.scalars[1] = 1;
+                }
+            fetch(b + gridDim.x);
+            continue;
+        }
+        for (unsigned i = threadIdx.x; i < PB_BUCKET_SLOTS; i += 256) { lkeys[i] = PB_EMPTY_KEY; lcnt[i] = 0; }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < KPL; ++j) {
+            const u64 key = kin[j];
+            if (key == PB_EMPTY_KEY) continue;
+            u32 s = (u32)part_hash(key) & (PB_BUCKET_SLOTS - 1);     // low hash bits: independent of the bucket digits
+            while (true) {
+                u64 prev = lkeys[s];
+                if (prev == PB_EMPTY_KEY) prev = atomicCAS(&lkeys[s], PB_EMPTY_KEY, key);
+                if (prev == PB_EMPTY_KEY || prev == key) { atomicAdd(&lcnt[s], 1u); break; }
+                s = (s + 1) & (PB_BUCKET_SLOTS - 1);
+            }
+        }
+        fetch(b + gridDim.x);                         // next bucket's loads fly during the emit below
+        __syncthreads();
+        // emit: every lane counts its occupied slots, one block-wide exclusive scan gives its output offset
+        u32 cnts[SPL];
+        u32 mine = 0;
+#pragma unroll
+        for (int j = 0; j < SPL; ++j) { cnts[j] = lcnt[threadIdx.x * SPL + j]; mine += cnts[j] != 0; }
+        u32 x = mine;
+        for (int o = 1; o < 64; o <<= 1) { const u32 y = __shfl_up(x, o, 64); if ((int)lane >= o) x += y; }
+        if (lane == 63) wtot[wave] = x;
+        __syncthreads();
+        u32 off = x - mine;
+        for (unsigned w = 0; w < wave; ++w) off += wtot[w];
+        u64 pos = bucket_base[b] + off;
+#pragma unroll
+        for (int j = 0; j < SPL; ++j)
+            if (cnts[j]) {
+                out_keys[pos] = lkeys[threadIdx.x * SPL + j];
+                out_counts[pos] = cnts[j];
+                ++pos;
+            }
+        if (threadIdx.x == 255) n_occ_out[b] = off + mine;
+        __syncthreads();
+    }
+}
+
+// close the gaps: bucket b's n_occ[b] records move from src[bucket_base[b]] to dst[dst_base[b]]; 16 lanes per bucket
+__global__ void __launch_bounds__(256)
+bucket_compact_kernel(const u64 *__restrict__ src_keys, const u32 *__restrict__ src_counts, const u64 *__restrict__ bucket_base,
+                      const u32 *__restrict__ n_occ, const u64 *__restrict__ dst_base, unsigned n_buckets,
+                      u64 *__restrict__ dst_keys, u32 *__restrict__ dst_counts)
+{
+    const unsigned sub = threadIdx.x & 15;
+    for (u64 b = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 4; b < n_buckets; b += ((u64)gridDim.x * blockDim.x) >> 4) {
+        const u32 n = n_occ[b];
+        const u64 sb = bucket_base[b], db = dst_base[b];
+        for (u32 i = sub; i < n; i += 16) {
+            dst_keys[db + i] = src_keys[sb + i];
+            dst_counts[db + i] = src_counts[sb + i];
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -574,6 +944,7 @@ void pb_destroy(pb_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     release(ctx->packed); release(ctx->nmask); release(ctx->table); release(ctx->d_hist); release(ctx->d_scalars);
     release(ctx->ret_keys); release(ctx->ret_counts); release(ctx->exp_keys); release(ctx->exp_counts); release(ctx->merge_table);
+    release(ctx->dist_keys); release(ctx->dist_counts); release(ctx->part_bucket1); release(ctx->part_bucket2); release(ctx->part_meta); release(ctx->part_out_counts); release(ctx->part_segs);
     for (auto &s : ctx->scratch) release(s);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
@@ -617,7 +988,6 @@ int pb_reads_length_hist(pb_ctx *ctx, uint64_t *hist, uint64_t hist_n)
     return PB_OK;
 }
 
-#define PB_STREAM_PAD_WORDS64 8      /* 512 positions of padding: a 160-mer window never leaves the buffer */
 
 int pb_reads_append(pb_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads, int ascii)
 {
@@ -663,18 +1033,65 @@ int pb_reads_append(pb_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, 
 
 } // extern "C"
 
+// ------------------------------------------------------------------------------------------------------
+// counting: host orchestration
+// ------------------------------------------------------------------------------------------------------
+static int finish_count(pb_ctx *ctx, uint64_t *occ_hist, uint64_t *max_occ)
+{
+    // histogram of the distinct arrays (K4a) + copy out
+    int rc;
+    if ((rc = ensure(ctx, ctx->d_hist, 65536 * 8)) != PB_OK) return rc;
+    HIPCHK(hipMemsetAsync(ctx->d_hist.p, 0, 65536 * 8, ctx->stream));
+    {
+        StageTimer tm(ctx, "hist");
+        if (ctx->n_distinct)
+            hist_array_kernel<<<grid_for(ctx->n_distinct, 256, 256 * 8), 256, 0, ctx->stream>>>((const u32 *)ctx->dist_counts.p, ctx->n_distinct,
+                                                                                               (u64 *)ctx->d_hist.p);
+        HIPCHK(hipGetLastError());
+        if ((rc = tm.stop()) != PB_OK) return rc;
+    }
+    std::vector<u64> h(65536);
+    HIPCHK(hipMemcpyAsync(h.data(), ctx->d_hist.p, 65536 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (occ_hist) for (int i = 0; i < PB_OCC_BINS; ++i) occ_hist[i] = h[i];
+    if (max_occ) { *max_occ = 0; for (int i = PB_COUNT_MAX; i > 0; --i) if (h[i]) { *max_occ = (u64)i; break; } }
+    return PB_OK;
+}
+
+// table (ctx->table) -> distinct arrays; sets n_distinct
 template <int W>
-static int count_impl(pb_ctx *ctx, unsigned k)
+static int table_to_arrays(pb_ctx *ctx, u64 upper_bound, bool append)
 {
     int rc;
-    if ((rc = ensure(ctx, ctx->d_scalars, 16 * 8)) != PB_OK) return rc;
-    if ((rc = ensure(ctx, ctx->d_hist, 65536 * 8)) != PB_OK) return rc;
-    // capacity: a power of two >= half the number of windows (distinct k-mers are a fraction of the
-    // instances at any useful coverage); doubled and redone if a probe sequence ever overflows.
+    const u64 base = append ? ctx->n_distinct : 0;
+    const u64 cap_out = std::max<u64>(base + upper_bound, 1);
+    if ((rc = ensure(ctx, ctx->dist_keys, cap_out * W * 8, append)) != PB_OK) return rc;
+    if ((rc = ensure(ctx, ctx->dist_counts, cap_out * 4, append)) != PB_OK) return rc;
+    TableView<W> tv{(u64 *)ctx->table.p, ctx->table_cap - 1};
+    HIPCHK(hipMemsetAsync(ctx->d_scalars.p, 0, 16 * 8, ctx->stream));
+    StageTimer tm(ctx, "compact");
+    table_to_arrays_kernel<W><<<grid_for(ctx->table_cap, 256, 256 * 8), 256, 0, ctx->stream>>>(
+        tv, (u64 *)ctx->dist_keys.p + base * W, (u32 *)ctx->dist_counts.p + base, cap_out - base, (u64 *)ctx->d_scalars.p);
+    HIPCHK(hipGetLastError());
+    if ((rc = tm.stop()) != PB_OK) return rc;
+    u64 n = 0;
+    HIPCHK(hipMemcpyAsync(&n, ctx->d_scalars.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (n > cap_out - base) { ctx->err = "distinct array overflow"; return PB_ENOMEM; }
+    ctx->n_distinct = base + n;
+    return PB_OK;
+}
+
+// v1: one lane per window, global-atomic hashing (any W)
+template <int W>
+static int count_direct(pb_ctx *ctx, unsigned k)
+{
+    int rc;
     u64 windows = ctx->stream_len > (u64)k * ctx->n_reads ? ctx->stream_len - (u64)(k - 1) * ctx->n_reads : 1;
     u64 cap = 1ull << 16;
     while (cap < windows / 2) cap <<= 1;
     float ms_count = 0;
+    const char *gc = getenv("PB_GRIDCAP");
     for (int attempt = 0; attempt < 8; ++attempt) {
         if ((rc = ensure(ctx, ctx->table, cap * PB_SLOT_WORDS(W) * 8)) != PB_OK) return rc;
         ctx->table_cap = cap;
@@ -687,7 +1104,7 @@ static int count_impl(pb_ctx *ctx, unsigned k)
         }
         StageTimer tm(ctx, "count");
         if (ctx->stream_len >= k) {
-            count_kernel<W><<<grid_for(ctx->stream_len, 256, getenv("PB_GRIDCAP") ? atoi(getenv("PB_GRIDCAP")) : 256 * 32), 256, 0, ctx->stream>>>(
+            count_kernel<W><<<grid_for(ctx->stream_len, 256, gc ? atoi(gc) : 256 * 32), 256, 0, ctx->stream>>>(
                 (const u64 *)ctx->packed.p, (const u64 *)ctx->nmask.p, ctx->stream_len, k, tv, 256u, (u64 *)ctx->d_scalars.p);
         }
         HIPCHK(hipGetLastError());
@@ -701,14 +1118,113 @@ static int count_impl(pb_ctx *ctx, unsigned k)
         if (attempt == 7) { ctx->err = "occurrence table overflow after 8 doublings"; return PB_ENOMEM; }
     }
     ctx->stage_ms["count"] = ms_count;
-    {
-        TableView<W> tv{(u64 *)ctx->table.p, ctx->table_cap - 1};
-        HIPCHK(hipMemsetAsync(ctx->d_hist.p, 0, 65536 * 8, ctx->stream));
-        StageTimer tm(ctx, "hist");
-        hist_kernel<W><<<grid_for(ctx->table_cap, 256, 256 * 8), 256, 0, ctx->stream>>>(tv, (u64 *)ctx->d_hist.p);
-        HIPCHK(hipGetLastError());
-        if ((rc = tm.stop()) != PB_OK) return rc;
+    ctx->stage_ms["part1"] = ctx->stage_ms["part2"] = ctx->stage_ms["bucket"] = ctx->stage_ms["seg_compact"] = 0.f;
+    return table_to_arrays<W>(ctx, std::min<u64>(ctx->n_instances, ctx->table_cap), false);
+}
+
+// v2: two-level hash partitioning + LDS-resident counting (k <= 32)
+static int count_partitioned(pb_ctx *ctx, unsigned k, bool *done)
+{
+    int rc;
+    *done = false;
+    const u64 windows = ctx->stream_len;          // upper bound on counted windows
+    unsigned logp = 10;
+    while (((u64)1536 << logp) < windows && logp < 20) ++logp;
+    if (((u64)1536 << logp) < windows) return PB_OK;          // too large for 2^20 buckets: caller uses v1
+    PartParams p;
+    p.l1 = (logp + 1) / 2;
+    p.l2 = logp - p.l1;
+    // a sub-stream holds 1/PB_XCD of a bucket if blocks are dealt evenly over the XCDs (observed: round-robin); 1.5x margin,
+    // anything beyond goes through the fallback table
+    p.cap1 = ((windows >> p.l1) / PB_XCD) * 3 / 2 + 8192;
+    const u64 nb1 = (1ull << p.l1) * PB_XCD, nb2 = 1ull << logp;
+    if ((rc = ensure(ctx, ctx->part_bucket1, nb1 * p.cap1 * 8)) != PB_OK) return rc;
+    if ((rc = ensure(ctx, ctx->part_bucket2, nb2 * PB_BUCKET_CAP * 8)) != PB_OK) return rc;
+    if ((rc = ensure(ctx, ctx->part_meta, (nb1 + 2 * nb2) * 4)) != PB_OK) return rc;
+    p.bucket1 = (u64 *)ctx->part_bucket1.p;
+    p.bucket2 = (u64 *)ctx->part_bucket2.p;
+    p.cursor1 = (u32 *)ctx->part_meta.p;
+    p.cursor2 = p.cursor1 + nb1;
+    p.flag2 = p.cursor2 + nb2;
+    // fallback table (v1 representation) for flagged buckets
+    u64 fcap = 1ull << 20;
+    for (int attempt = 0; attempt < 10; ++attempt) {
+        if ((rc = ensure(ctx, ctx->table, fcap * 16)) != PB_OK) return rc;
+        ctx->table_cap = fcap;
+        p.fallback = TableView<1>{(u64 *)ctx->table.p, fcap - 1};
+        p.scalars = (u64 *)ctx->d_scalars.p;
+        HIPCHK(hipMemsetAsync(ctx->d_scalars.p, 0, 16 * 8, ctx->stream));
+        HIPCHK(hipMemsetAsync(ctx->part_meta.p, 0, (nb1 + 2 * nb2) * 4, ctx->stream));
+        {
+            StageTimer ti(ctx, "table_init");
+            table_init_kernel<1><<<grid_for(fcap * 2, 256, 256 * 32), 256, 0, ctx->stream>>>(p.fallback.slots, fcap);
+            if ((rc = ti.stop()) != PB_OK) return rc;
+        }
+        const u64 cap_out = std::max<u64>(windows, 1);
+        DevBuf &tmp_keys = ctx->part_bucket1;      // level-1 buckets are dead after part2: reuse them as the segmented output
+        DevBuf &tmp_counts = ctx->part_out_counts;
+        if ((rc = ensure(ctx, tmp_counts, cap_out * 4)) != PB_OK) return rc;
+        // per-bucket offsets: [bucket_base u64 nb2][dst_base u64 nb2][block sums u64 1024][n_occ u32 nb2]
+        if ((rc = ensure(ctx, ctx->part_segs, nb2 * 20 + 1024 * 8 + 64)) != PB_OK) return rc;
+        u64 *bucket_base = (u64 *)ctx->part_segs.p, *dst_base = bucket_base + nb2, *blk_sums = dst_base + nb2;
+        u32 *n_occ = (u32 *)(blk_sums + 1024);
+        HIPCHK(hipMemsetAsync(n_occ, 0, nb2 * 4, ctx->stream));
+        {
+            StageTimer t1(ctx, "part1");
+            const u64 n_tiles = (ctx->stream_len + PB_TILE - 1) / PB_TILE;
+            part1_kernel<<<grid_for(n_tiles, 1, 256 * 4), PB_PART_THREADS, 0, ctx->stream>>>((const u64 *)ctx->packed.p, (const u64 *)ctx->nmask.p,
+                                                                                ctx->stream_len, (ctx->stream_len + 63) / 64 + PB_STREAM_PAD_WORDS64, k, p);
+            HIPCHK(hipGetLastError());
+            if ((rc = t1.stop()) != PB_OK) return rc;
+        }
+        {
+            StageTimer t2(ctx, "part2");
+            const unsigned tiles_per_b1 = (unsigned)std::min<u64>((p.cap1 + PB_TILE - 1) / PB_TILE, 65535);
+            part2_kernel<<<dim3(tiles_per_b1, (unsigned)nb1), PB_PART_THREADS, 0, ctx->stream>>>(p);   // nb1 counts sub-streams
+            HIPCHK(hipGetLastError());
+            if ((rc = t2.stop()) != PB_OK) return rc;
+        }
+        const unsigned scan_blocks = (unsigned)(nb2 / 1024);
+        {
+            StageTimer t3(ctx, "bucket");
+            scan_local_kernel<<<scan_blocks, 256, 0, ctx->stream>>>(p.cursor2, PB_BUCKET_CAP, bucket_base, blk_sums);
+            scan_sums_kernel<<<1, 1024, 0, ctx->stream>>>(blk_sums, scan_blocks, (u64 *)ctx->d_scalars.p + 3);
+            scan_add_kernel<<<scan_blocks, 256, 0, ctx->stream>>>(bucket_base, blk_sums);
+            bucket_count_kernel<<<grid_for(nb2, 1, 256 * 64), 256, 0, ctx->stream>>>(p, (u64 *)tmp_keys.p, (u32 *)tmp_counts.p, bucket_base, n_occ);
+            HIPCHK(hipGetLastError());
+            if ((rc = t3.stop()) != PB_OK) return rc;
+        }
+        u64 sc[5];
+        {
+            StageTimer t4(ctx, "seg_compact");
+            scan_local_kernel<<<scan_blocks, 256, 0, ctx->stream>>>(n_occ, 0xFFFFFFFFu, dst_base, blk_sums);
+            scan_sums_kernel<<<1, 1024, 0, ctx->stream>>>(blk_sums, scan_blocks, (u64 *)ctx->d_scalars.p + 4);
+            scan_add_kernel<<<scan_blocks, 256, 0, ctx->stream>>>(dst_base, blk_sums);
+            HIPCHK(hipMemcpyAsync(sc, ctx->d_scalars.p, 40, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            if (sc[1] == 0) {
+                const u64 total = sc[4];
+                if ((rc = ensure(ctx, ctx->dist_keys, std::max<u64>(total + fcap, 1) * 8)) != PB_OK) return rc;
+                if ((rc = ensure(ctx, ctx->dist_counts, std::max<u64>(total + fcap, 1) * 4)) != PB_OK) return rc;
+                bucket_compact_kernel<<<grid_for(nb2 * 16, 256, 256 * 16), 256, 0, ctx->stream>>>(
+                    (const u64 *)tmp_keys.p, (const u32 *)tmp_counts.p, bucket_base, n_occ, dst_base, (unsigned)nb2, (u64 *)ctx->dist_keys.p,
+                    (u32 *)ctx->dist_counts.p);
+                HIPCHK(hipGetLastError());
+            }
+            if ((rc = t4.stop()) != PB_OK) return rc;
+        }
+        if (sc[1] == 0) {
+            ctx->n_instances = sc[0];
+            ctx->n_distinct = sc[4];
+            break;
+        }
+        fcap <<= 2;                     // the fallback table itself overflowed: retry with a larger one
+        if (attempt == 9) { ctx->err = "fallback table overflow"; return PB_ENOMEM; }
     }
+    ctx->stage_ms["count"] = ctx->stage_ms["part1"] + ctx->stage_ms["part2"] + ctx->stage_ms["bucket"] + ctx->stage_ms["seg_compact"];
+    // records counted through the fallback table are appended
+    if ((rc = table_to_arrays<1>(ctx, ctx->table_cap, true)) != PB_OK) return rc;
+    *done = true;
     return PB_OK;
 }
 
@@ -722,69 +1238,55 @@ int pb_count(pb_ctx *ctx, unsigned k, uint64_t *occ_hist, uint64_t *max_occ, uin
     ctx->k = k;
     ctx->W = (int)((k + 31) / 32);
     ctx->n_retained = 0;
+    ctx->n_distinct = 0;
     int rc;
-    switch (ctx->W) {
-    case 1: rc = count_impl<1>(ctx, k); break;
-    case 2: rc = count_impl<2>(ctx, k); break;
-    case 3: rc = count_impl<3>(ctx, k); break;
-    case 4: rc = count_impl<4>(ctx, k); break;
-    default: rc = count_impl<5>(ctx, k); break;
+    if ((rc = ensure(ctx, ctx->d_scalars, 16 * 8)) != PB_OK) return rc;
+    bool done = false;
+    const char *force = getenv("PB_COUNT_PATH");       // "direct" | "partitioned" (development / A-B runs)
+    const bool want_part = ctx->W == 1 && ctx->stream_len >= k &&
+                           (force ? strcmp(force, "partitioned") == 0 : ctx->stream_len >= (1ull << 22));
+    if (want_part && !(force && strcmp(force, "direct") == 0)) {
+        if ((rc = count_partitioned(ctx, k, &done)) != PB_OK) return rc;
     }
-    if (rc != PB_OK) return rc;
-    std::vector<u64> h(65536);
-    HIPCHK(hipMemcpyAsync(h.data(), ctx->d_hist.p, 65536 * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    ctx->n_distinct = h[65535];
-    if (occ_hist) { for (int i = 0; i < PB_OCC_BINS; ++i) occ_hist[i] = h[i]; }
-    if (max_occ) { *max_occ = 0; for (int i = PB_COUNT_MAX; i > 0; --i) if (h[i]) { *max_occ = (u64)i; break; } }
+    if (!done) {
+        switch (ctx->W) {
+        case 1: rc = count_direct<1>(ctx, k); break;
+        case 2: rc = count_direct<2>(ctx, k); break;
+        case 3: rc = count_direct<3>(ctx, k); break;
+        case 4: rc = count_direct<4>(ctx, k); break;
+        default: rc = count_direct<5>(ctx, k); break;
+        }
+        if (rc != PB_OK) return rc;
+    }
+    ctx->count_path = done ? 2 : 1;
+    if ((rc = finish_count(ctx, occ_hist, max_occ)) != PB_OK) return rc;
     if (n_instances) *n_instances = ctx->n_instances;
     if (n_distinct) *n_distinct = ctx->n_distinct;
     return PB_OK;
 }
 
-} // extern "C"
-
-template <int W>
-static int compact_impl(pb_ctx *ctx, unsigned min_occ, DevBuf &keys, DevBuf &counts, u64 *n_out)
-{
-    int rc;
-    const u64 cap_out = std::max<u64>(ctx->n_distinct, 1);
-    if ((rc = ensure(ctx, keys, cap_out * W * 8)) != PB_OK) return rc;
-    if ((rc = ensure(ctx, counts, cap_out * 4)) != PB_OK) return rc;
-    TableView<W> tv{(u64 *)ctx->table.p, ctx->table_cap - 1};
-    HIPCHK(hipMemsetAsync(ctx->d_scalars.p, 0, 16 * 8, ctx->stream));
-    StageTimer tm(ctx, "compact");
-    compact_kernel<W><<<grid_for(ctx->table_cap, 256, 256 * 8), 256, 0, ctx->stream>>>(
-        tv, min_occ, (u64 *)keys.p, (u32 *)counts.p, cap_out, (u64 *)ctx->d_scalars.p);
-    HIPCHK(hipGetLastError());
-    if ((rc = tm.stop()) != PB_OK) return rc;
-    HIPCHK(hipMemcpyAsync(n_out, ctx->d_scalars.p, 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    return PB_OK;
-}
-
-static int compact_dispatch(pb_ctx *ctx, unsigned min_occ, DevBuf &keys, DevBuf &counts, u64 *n_out)
-{
-    switch (ctx->W) {
-    case 1: return compact_impl<1>(ctx, min_occ, keys, counts, n_out);
-    case 2: return compact_impl<2>(ctx, min_occ, keys, counts, n_out);
-    case 3: return compact_impl<3>(ctx, min_occ, keys, counts, n_out);
-    case 4: return compact_impl<4>(ctx, min_occ, keys, counts, n_out);
-    default: return compact_impl<5>(ctx, min_occ, keys, counts, n_out);
-    }
-}
-
-extern "C" {
-
 int pb_retain(pb_ctx *ctx, unsigned min_occ, uint64_t *n_keys)
 {
-    if (!ctx || ctx->W == 0 || !ctx->table.p) { if (ctx) ctx->err = "pb_retain before pb_count"; return PB_EINVAL; }
+    if (!ctx || ctx->W == 0) { if (ctx) ctx->err = "pb_retain before pb_count"; return PB_EINVAL; }
     (void)hipSetDevice(ctx->dev);
     int rc;
     const int W = ctx->W;
     DevBuf &ck = ctx->scratch[2], &cc = ctx->scratch[3];
     u64 n = 0;
-    if ((rc = compact_dispatch(ctx, min_occ, ck, cc, &n)) != PB_OK) return rc;
+    const u64 nd = ctx->n_distinct;
+    if ((rc = ensure(ctx, ck, std::max<u64>(nd, 1) * W * 8)) != PB_OK) return rc;
+    if ((rc = ensure(ctx, cc, std::max<u64>(nd, 1) * 4)) != PB_OK) return rc;
+    HIPCHK(hipMemsetAsync(ctx->d_scalars.p, 0, 16 * 8, ctx->stream));
+    {
+        StageTimer tm(ctx, "filter");
+        if (nd)
+            filter_array_kernel<<<grid_for(nd, 256, 256 * 8), 256, 0, ctx->stream>>>((const u64 *)ctx->dist_keys.p, (const u32 *)ctx->dist_counts.p, nd, W,
+                                                                                     min_occ, (u64 *)ck.p, (u32 *)cc.p, (u64 *)ctx->d_scalars.p);
+        HIPCHK(hipGetLastError());
+        if ((rc = tm.stop()) != PB_OK) return rc;
+    }
+    HIPCHK(hipMemcpyAsync(&n, ctx->d_scalars.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->n_retained = n;
     if ((rc = ensure(ctx, ctx->ret_keys, std::max<u64>(n, 1) * W * 8)) != PB_OK) return rc;
     if ((rc = ensure(ctx, ctx->ret_counts, std::max<u64>(n, 1) * 2)) != PB_OK) return rc;
@@ -827,16 +1329,13 @@ int pb_fetch_retained(pb_ctx *ctx, uint64_t *keys, uint16_t *counts)
 
 int pb_fetch_all(pb_ctx *ctx, uint64_t *keys, uint32_t *counts, uint64_t cap, uint64_t *n)
 {
-    if (!ctx || ctx->W == 0 || !ctx->table.p) return PB_EINVAL;
+    if (!ctx || ctx->W == 0) return PB_EINVAL;
     (void)hipSetDevice(ctx->dev);
-    int rc;
-    DevBuf &ck = ctx->scratch[2], &cc = ctx->scratch[3];
-    u64 m = 0;
-    if ((rc = compact_dispatch(ctx, 1, ck, cc, &m)) != PB_OK) return rc;
+    const u64 m = ctx->n_distinct;
     if (n) *n = m;
     const u64 take = std::min<u64>(m, (u64)cap);
-    if (take && keys) HIPCHK(hipMemcpyAsync(keys, ck.p, take * ctx->W * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (take && counts) HIPCHK(hipMemcpyAsync(counts, cc.p, take * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (take && keys) HIPCHK(hipMemcpyAsync(keys, ctx->dist_keys.p, take * ctx->W * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (take && counts) HIPCHK(hipMemcpyAsync(counts, ctx->dist_counts.p, take * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return PB_OK;
 }
@@ -850,35 +1349,52 @@ int pb_last_kernel_ms(const pb_ctx *ctx, const char *stage, float *ms)
     return PB_OK;
 }
 
-} // extern "C"
-
-template <int W>
-static int export_impl(pb_ctx *ctx, unsigned n_parts, uint64_t *part_counts)
+// ---- X1 ---------------------------------------------------------------------------------------------
+int pb_export_begin(pb_ctx *ctx, int n_parts, uint64_t *part_counts)
 {
+    if (!ctx || !part_counts || n_parts < 1 || n_parts > PB_MAX_PARTS || ctx->W == 0) return PB_EINVAL;
+    (void)hipSetDevice(ctx->dev);
     int rc;
-    TableView<W> tv{(u64 *)ctx->table.p, ctx->table_cap - 1};
-    if ((rc = ensure(ctx, ctx->d_scalars, 16 * 8)) != PB_OK) return rc;
+    const int W = ctx->W;
+    const u64 nd = ctx->n_distinct;
     DevBuf &pc = ctx->scratch[0];
     if ((rc = ensure(ctx, pc, PB_MAX_PARTS * 8 * 2)) != PB_OK) return rc;
     HIPCHK(hipMemsetAsync(pc.p, 0, PB_MAX_PARTS * 8 * 2, ctx->stream));
     StageTimer tm(ctx, "export");
-    part_count_kernel<W><<<grid_for(ctx->table_cap, 256, 256 * 8), 256, 0, ctx->stream>>>(tv, n_parts, (u64 *)pc.p);
+    if (nd)
+        part_count_kernel<<<grid_for(nd, 256, 256 * 8), 256, 0, ctx->stream>>>((const u64 *)ctx->dist_keys.p, (const u32 *)ctx->dist_counts.p, nd, W,
+                                                                               (unsigned)n_parts, (u64 *)pc.p);
     u64 h[PB_MAX_PARTS];
     HIPCHK(hipMemcpyAsync(h, pc.p, n_parts * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     u64 cur[PB_MAX_PARTS], total = 0;
-    for (unsigned i = 0; i < n_parts; ++i) { cur[i] = total; total += h[i]; part_counts[i] = h[i]; }
+    for (int i = 0; i < n_parts; ++i) { cur[i] = total; total += h[i]; part_counts[i] = h[i]; }
     ctx->exp_total = total;
-    ctx->exp_parts = n_parts;
+    ctx->exp_parts = (unsigned)n_parts;
     if ((rc = ensure(ctx, ctx->exp_keys, std::max<u64>(total, 1) * W * 8)) != PB_OK) return rc;
     if ((rc = ensure(ctx, ctx->exp_counts, std::max<u64>(total, 1) * 4)) != PB_OK) return rc;
     u64 *cursors = (u64 *)pc.p + PB_MAX_PARTS;
     HIPCHK(hipMemcpyAsync(cursors, cur, n_parts * 8, hipMemcpyHostToDevice, ctx->stream));
-    part_scatter_kernel<W><<<grid_for(ctx->table_cap, 256, 256 * 8), 256, 0, ctx->stream>>>(tv, n_parts, cursors, (u64 *)ctx->exp_keys.p,
-                                                                                         (u32 *)ctx->exp_counts.p);
+    if (nd)
+        part_scatter_kernel<<<grid_for(nd, 256, 256 * 8), 256, 0, ctx->stream>>>((const u64 *)ctx->dist_keys.p, (const u32 *)ctx->dist_counts.p, nd, W,
+                                                                                 (unsigned)n_parts, cursors, (u64 *)ctx->exp_keys.p, (u32 *)ctx->exp_counts.p);
     HIPCHK(hipGetLastError());
     return tm.stop();
 }
+
+int pb_export_copy(pb_ctx *ctx, void *dev_keys, void *dev_counts)
+{
+    if (!ctx || ctx->exp_parts == 0) return PB_EINVAL;
+    (void)hipSetDevice(ctx->dev);
+    if (ctx->exp_total) {
+        HIPCHK(hipMemcpyAsync(dev_keys, ctx->exp_keys.p, ctx->exp_total * ctx->W * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(dev_counts, ctx->exp_counts.p, ctx->exp_total * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return PB_OK;
+}
+
+} // extern "C"
 
 template <int W>
 static int merge_add_impl(pb_ctx *ctx, const void *dev_keys, const void *dev_counts, u64 n)
@@ -895,6 +1411,7 @@ static int merge_add_impl(pb_ctx *ctx, const void *dev_keys, const void *dev_cou
     HIPCHK(hipMemcpyAsync(sc, ctx->d_scalars.p, 16, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (sc[1]) { ctx->err = "merge table overflow (expected_records too small)"; return PB_ENOMEM; }
+    ctx->merge_records += n;
     return PB_OK;
 }
 
@@ -904,23 +1421,11 @@ static int merge_begin_impl(pb_ctx *ctx, u64 cap)
     int rc;
     if ((rc = ensure(ctx, ctx->merge_table, cap * PB_SLOT_WORDS(W) * 8)) != PB_OK) return rc;
     ctx->merge_cap = cap;
+    ctx->merge_records = 0;
     table_init_kernel<W><<<grid_for(cap * PB_SLOT_WORDS(W), 256, 256 * 32), 256, 0, ctx->stream>>>((u64 *)ctx->merge_table.p, cap);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return PB_OK;
-}
-
-template <int W>
-static int hist_only_impl(pb_ctx *ctx)
-{
-    int rc;
-    if ((rc = ensure(ctx, ctx->d_hist, 65536 * 8)) != PB_OK) return rc;
-    TableView<W> tv{(u64 *)ctx->table.p, ctx->table_cap - 1};
-    HIPCHK(hipMemsetAsync(ctx->d_hist.p, 0, 65536 * 8, ctx->stream));
-    StageTimer tm(ctx, "hist");
-    hist_kernel<W><<<grid_for(ctx->table_cap, 256, 256 * 8), 256, 0, ctx->stream>>>(tv, (u64 *)ctx->d_hist.p);
-    HIPCHK(hipGetLastError());
-    return tm.stop();
 }
 
 #define PB_DISPATCH_W(ctx, fn, ...)                                   \
@@ -928,25 +1433,6 @@ static int hist_only_impl(pb_ctx *ctx)
      : (ctx)->W == 4 ? fn<4>(__VA_ARGS__) : fn<5>(__VA_ARGS__))
 
 extern "C" {
-
-int pb_export_begin(pb_ctx *ctx, int n_parts, uint64_t *part_counts)
-{
-    if (!ctx || !part_counts || n_parts < 1 || n_parts > PB_MAX_PARTS || ctx->W == 0 || !ctx->table.p) return PB_EINVAL;
-    (void)hipSetDevice(ctx->dev);
-    return PB_DISPATCH_W(ctx, export_impl, ctx, (unsigned)n_parts, part_counts);
-}
-
-int pb_export_copy(pb_ctx *ctx, void *dev_keys, void *dev_counts)
-{
-    if (!ctx || ctx->exp_parts == 0) return PB_EINVAL;
-    (void)hipSetDevice(ctx->dev);
-    if (ctx->exp_total) {
-        HIPCHK(hipMemcpyAsync(dev_keys, ctx->exp_keys.p, ctx->exp_total * ctx->W * 8, hipMemcpyDeviceToDevice, ctx->stream));
-        HIPCHK(hipMemcpyAsync(dev_counts, ctx->exp_counts.p, ctx->exp_total * 4, hipMemcpyDeviceToDevice, ctx->stream));
-    }
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    return PB_OK;
-}
 
 int pb_merge_begin(pb_ctx *ctx, unsigned k, uint64_t expected_records)
 {
@@ -976,14 +1462,10 @@ int pb_merge_end(pb_ctx *ctx, uint64_t *occ_hist, uint64_t *max_occ, uint64_t *n
     ctx->table_cap = ctx->merge_cap;
     ctx->merge_cap = 0;
     ctx->n_retained = 0;
-    int rc = PB_DISPATCH_W(ctx, hist_only_impl, ctx);
+    ctx->n_distinct = 0;
+    int rc = PB_DISPATCH_W(ctx, table_to_arrays, ctx, std::min<u64>(ctx->merge_records, ctx->table_cap), false);
     if (rc != PB_OK) return rc;
-    std::vector<u64> h(65536);
-    HIPCHK(hipMemcpyAsync(h.data(), ctx->d_hist.p, 65536 * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    ctx->n_distinct = h[65535];
-    if (occ_hist) for (int i = 0; i < PB_OCC_BINS; ++i) occ_hist[i] = h[i];
-    if (max_occ) { *max_occ = 0; for (int i = PB_COUNT_MAX; i > 0; --i) if (h[i]) { *max_occ = (u64)i; break; } }
+    if ((rc = finish_count(ctx, occ_hist, max_occ)) != PB_OK) return rc;
     if (n_distinct) *n_distinct = ctx->n_distinct;
     return PB_OK;
 }

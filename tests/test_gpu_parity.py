@@ -196,3 +196,50 @@ def test_export_buckets_and_merge_roundtrip(k, gpu, oracle_built):
     gk, gc = g.fetch_retained()
     assert np.array_equal(gk, ok)
     assert np.array_equal(gc, np.minimum(ocn.astype(np.int64) * 2, 65534).astype(np.uint16))
+
+
+@pytest.mark.parametrize("k", [32, 21, 13, 31])
+def test_partitioned_count_path_matches_oracle(k, gpu, oracle_built, monkeypatch):
+    """The two-level partition + LDS counting path (used for large inputs) forced on a small input."""
+    from platanus_b_amd import synth
+    monkeypatch.setenv("PB_COUNT_PATH", "partitioned")
+    r1, r2 = synth.make_reads(60_000, 60, seed=40 + k, n_rate=0.002)
+    codes = np.concatenate([r1, r2])
+    n, L = codes.shape
+    off = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
+    oc = _oracle(codes, off, k, oracle_built)
+    ohist, omax = oc.occ_hist()
+    g = gpu(0)
+    g.reads_append_matrix(codes)
+    hist = g.make_kmer_read_distribution(k)
+    assert g.kernel_ms("part1") > 0          # really took the partitioned path
+    assert np.array_equal(hist, ohist) and g.max_occ == omax
+    assert g.n_distinct == int(ohist.sum())
+    for cutoff in (1, 3):
+        ok, ocn = oc.retain(cutoff)
+        assert g.retain(cutoff) == len(ok)
+        gk, gc = g.fetch_retained()
+        assert np.array_equal(gk, ok) and np.array_equal(gc, ocn)
+
+
+def test_partitioned_path_heavy_hitter_goes_through_fallback(gpu, oracle_built, monkeypatch):
+    """One k-mer with a count far above a bucket's capacity (poly-A reads): the bucket is flagged and counted through
+    the global fallback table; results must not change."""
+    from platanus_b_amd import synth
+    monkeypatch.setenv("PB_COUNT_PATH", "partitioned")
+    r1, r2 = synth.make_reads(20_000, 30, seed=77)
+    poly = np.zeros((3000, 150), dtype=np.uint8)          # 3000 poly-A reads -> one 32-mer with 357000 instances
+    codes = np.concatenate([r1, poly, r2])
+    n, L = codes.shape
+    off = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
+    oc = _oracle(codes, off, 32, oracle_built)
+    ohist, omax = oc.occ_hist()
+    g = gpu(0)
+    g.reads_append_matrix(codes)
+    hist = g.make_kmer_read_distribution(32)
+    assert omax == 65534
+    assert np.array_equal(hist, ohist) and g.max_occ == omax
+    ok, ocn = oc.retain(2)
+    g.retain(2)
+    gk, gc = g.fetch_retained()
+    assert np.array_equal(gk, ok) and np.array_equal(gc, ocn)
