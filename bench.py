@@ -164,9 +164,13 @@ def main():
         partitioned = parts["part1"] > 0
         kernel = ("part1_kernel + part2_kernel + bucket_count_kernel + bucket_compact_kernel (partitioned counting pass)"
                   if partitioned else "count_kernel<1> (direct global-atomic counting pass)")
+        # HBM bytes per counting pass from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes
+        # of this same command, corrected as MI355X_MICROARCH.md prescribes): profiles/r01_hbm_traffic.json.  Only quoted
+        # when the run is the profiled workload and path.
         traffic = None
-        if os.environ.get("PB_HBM_TRAFFIC_BYTES"):       # measured with rocprofv3 --pmc in a separate run (profiles/)
-            traffic = float(os.environ["PB_HBM_TRAFFIC_BYTES"])
+        tj = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+        if partitioned and a.genome == GENOME and world == 1 and os.path.exists(tj):
+            traffic = json.load(open(tj)).get("hbm_bytes_per_counting_pass")
         out = {
             "metric": "k-mers/sec", "value": total_instances * a.steps / dt, "unit": "k-mers/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
