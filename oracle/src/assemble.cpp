@@ -142,7 +142,7 @@ struct Run {
     {
         Counter<W> &c = counter<W>();
         c.table.resize(dh_size);
-        graph<W>().save_edge_kmers(c.table, next_k);
+        graph<W>().save_edge_kmers([&](const Key<W> &key, u16 v) { c.table.put(key, v); }, next_k);
         if (opt.verbose) std::cerr << "extracting reads (containing kmer used in contig assemble)..." << std::endl;
         rfp = c.pickup_reads_matching_table(rfp);
         c.table.release();
@@ -184,7 +184,10 @@ struct Run {
         update_dh_size<WP, WN>();
         DHash<WN> tmp;
         tmp.resize(dh_size);
-        graph<WP>().template save_contig<WN>(kk, (avg_len - kk + 1.0) / (avg_len - prev_k + 1.0), tmp);
+        graph<WP>().template save_contig<WN>(kk, (avg_len - kk + 1.0) / (avg_len - prev_k + 1.0), [&](const Key<WN> &key, u16 occ) {
+            const u64 s = tmp.find_any(key);
+            if (tmp.vals[s] < occ) { tmp.vals[s] = occ; tmp.keys[s] = key; }
+        });
         graph<WP>().delete_all();
         if (opt.verbose) std::cerr << "K = " << kk << ", loading kmers from contigs..." << std::endl;
         counter<WN>().table = std::move(tmp);
@@ -211,7 +214,10 @@ struct Run {
         if (W > 1) dh_size = table_size_for_memory(memory, W);
         DHash<W> tmp;
         tmp.resize(dh_size);
-        g.template save_contig<W>(kk, 1.0, tmp);
+        g.template save_contig<W>(kk, 1.0, [&](const Key<W> &key, u16 occ) {
+            const u64 s = tmp.find_any(key);
+            if (tmp.vals[s] < occ) { tmp.vals[s] = occ; tmp.keys[s] = key; }
+        });
         g.delete_all();
         c.table = std::move(tmp);
         c.count_reads_considering_table(kk, all_reads);

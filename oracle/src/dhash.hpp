@@ -6,11 +6,12 @@
 //                                                                            doubleHash.h:98-115
 // The slot a key lands in is part of the observable result (PREFIX_kmer_occ.bin, doubleHash.h:266-278).
 #pragma once
-#include "kmer.hpp"
+#include "../../platanus_b_amd/host/kmer.hpp"
 #include <vector>
 #include <stdexcept>
 
 namespace pbo {
+using namespace pbh;
 
 template <int W>
 struct DHash {

@@ -1,6 +1,4 @@
-// TEST INFRASTRUCTURE ONLY -- CPU restatement ("oracle") of Platanus_B's k-mer primitives.
-// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use anything under oracle/.
-//
+// Host-side k-mer primitives (shared by the product's C++ host and, for the same arithmetic, by the oracle).
 // Restates (does not copy) the reference's key types:
 //   * 2-bit code A=0 C=1 G=2 T=3, N=4, other -> 46            reference common.h:256-257
 //   * Kmer31  (k<=32, one u64; base i of the k-mer, 0 = 5' end, at bit 2*(k-1-i))   kmer.h:84-191
@@ -13,7 +11,7 @@
 #include <cstring>
 #include <functional>
 
-namespace pbo {
+namespace pbh {
 
 typedef uint64_t u64;
 typedef uint16_t u16;
@@ -133,4 +131,4 @@ struct Kmer {
     void set_forward(const Key<W> &f) { fwd = f; rev = revcomp(f, k); }
 };
 
-} // namespace pbo
+} // namespace pbh
