@@ -96,6 +96,33 @@ int pb_merge_begin(pb_ctx *ctx, unsigned k, uint64_t expected_records);
 int pb_merge_add(pb_ctx *ctx, const void *dev_keys, const void *dev_counts, uint64_t n);
 int pb_merge_end(pb_ctx *ctx, uint64_t *occ_hist, uint64_t *max_occ, uint64_t *n_distinct);
 
+/* ---- graph stage: device part of BruijnGraph::makeInitialBruijnGraph (graph.h:289-579) ------------------------ */
+/* On the retained, sorted set of the last pb_retain (n keys).  For retained k-mer i in its canonical orientation:
+ *   adj[i]      = (left flags << 4) | right flags; bit b of a nibble is set iff the predecessor / successor with
+ *                 base b is retained (the 8 counter.findValue probes of graph.h:352-380)
+ *   nbr[2i]     right side, nbr[2i+1] left side: when exactly one flag is set on that side,
+ *                 (index of that neighbour in the sorted set << 1) | flip, flip = 1 if the neighbour k-mer as reached is
+ *                 the reverse complement of its canonical key; 0xFFFFFFFF otherwise.
+ * With these two arrays the host replays the reference's DFS (visiting order, strands, cut points of cycles) in O(n)
+ * array steps instead of hash probes; see platanus_b_amd/host/device_graph.hpp. */
+int pb_graph_adjacency(pb_ctx *ctx, uint8_t *adj, uint32_t *nbr);
+
+/* ---- multi-k rounds (assemble.cpp:392-498) ------------------------------------------------------------------- */
+/* saveEdgeKmer + pickupReadMatchedEdgeKmer (graph.h:1877-1939, counter.h:869-910): keep a read iff one of its N-free
+ * k-mers (k = the finished graph's k) is among edge_keys[n_edge*W] (canonical).  Cumulative like the reference's readFP:
+ * a dropped read stays dropped until pb_reads_restore (= allReadFP, assemble.cpp:164-171).  Dropped reads are masked
+ * out of every later counting call. */
+int pb_reads_filter(pb_ctx *ctx, unsigned k, const uint64_t *edge_keys, uint64_t n_edge, uint64_t *n_kept);
+int pb_reads_restore(pb_ctx *ctx);
+/* saveContig<NEXT> (graph.h:1655-1771): every next-k k-mer of contig string c (codes 0..3, offsets[n_contigs+1]) gets
+ * value = max(value, values[c]); values[c] == 0 writes nothing.  The table stays resident for the next call. */
+int pb_contig_table_build(pb_ctx *ctx, unsigned k, const uint8_t *bases, const uint64_t *offsets, const uint16_t *values,
+                          uint64_t n_contigs, uint64_t *n_windows);
+/* makeKmerReadDistributionConsideringPreviousGraph (counter.h:662-750): k-mers of the (filtered) reads that are absent
+ * from the contig table are counted; result set = contig table entries (contig coverage) + those read k-mers.
+ * Afterwards pb_retain / pb_fetch_* / pb_graph_adjacency work on that set. */
+int pb_count_considering_contigs(pb_ctx *ctx, unsigned k, uint64_t *occ_hist, uint64_t *max_occ, uint64_t *n_distinct);
+
 /* ---- timing of the last call, measured with HIP events on the library's stream ------------------------- */
 /* stage names: "pack", "count", "hist", "compact", "sort", "adjacency", ... ; returns PB_EINVAL if unknown */
 int pb_last_kernel_ms(const pb_ctx *ctx, const char *stage, float *ms);

@@ -2,6 +2,7 @@
 #include "assemble.hpp"
 #include "counter.hpp"
 #include "fastx.hpp"
+#include "../../platanus_b_amd/host/schedule.hpp"
 #include <cstring>
 #include <memory>
 

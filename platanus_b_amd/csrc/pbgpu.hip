@@ -61,6 +61,16 @@ struct pb_ctx {
     u64 exp_total = 0, merge_cap = 0, merge_records = 0;
     unsigned exp_parts = 0;
 
+    // graph stage / multi-k rounds
+    DevBuf index_table;                 // retained key -> index + 1
+    DevBuf nmask_cur, alive, d_read_start;   // filtered read set: working mask copy, per-read flag, stream starts
+    std::vector<u64> read_start;        // host copy: stream position of every read + final sentinel (= stream_len)
+    size_t read_start_dev_n = 0;
+    bool mask_filtered = false;
+    DevBuf contig_packed, contig_mask, ctable;   // contig-derived next-k table (saveContig)
+    u64 ctable_cap = 0;
+    unsigned ctable_k = 0;
+
     // scratch
     DevBuf scratch[6];
 };
@@ -945,6 +955,8 @@ void pb_destroy(pb_ctx *ctx)
     release(ctx->packed); release(ctx->nmask); release(ctx->table); release(ctx->d_hist); release(ctx->d_scalars);
     release(ctx->ret_keys); release(ctx->ret_counts); release(ctx->exp_keys); release(ctx->exp_counts); release(ctx->merge_table);
     release(ctx->dist_keys); release(ctx->dist_counts); release(ctx->part_bucket1); release(ctx->part_bucket2); release(ctx->part_meta); release(ctx->part_out_counts); release(ctx->part_segs);
+    release(ctx->index_table); release(ctx->nmask_cur); release(ctx->alive); release(ctx->d_read_start);
+    release(ctx->contig_packed); release(ctx->contig_mask); release(ctx->ctable);
     for (auto &s : ctx->scratch) release(s);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
@@ -970,6 +982,9 @@ int pb_reads_clear(pb_ctx *ctx)
     if (!ctx) return PB_EINVAL;
     ctx->n_reads = ctx->n_bases = ctx->stream_len = 0;
     ctx->len_hist.clear();
+    ctx->read_start.clear();
+    ctx->read_start_dev_n = 0;
+    ctx->mask_filtered = false;
     return PB_OK;
 }
 
@@ -1025,6 +1040,11 @@ int pb_reads_append(pb_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, 
         (u64 *)ctx->nmask.p, first64, n64, ascii);
     HIPCHK(hipGetLastError());
     if ((rc = tm.stop()) != PB_OK) return rc;
+    if (!ctx->read_start.empty()) ctx->read_start.pop_back();
+    for (u64 r = 0; r < n_reads; ++r) ctx->read_start.push_back(old_len + rel[r] + r);
+    ctx->read_start.push_back(new_len);
+    ctx->read_start_dev_n = 0;
+    ctx->mask_filtered = false;
     ctx->stream_len = new_len;
     ctx->n_reads += n_reads;
     ctx->n_bases += n_new_bases;
@@ -1036,6 +1056,7 @@ int pb_reads_append(pb_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, 
 // ------------------------------------------------------------------------------------------------------
 // counting: host orchestration
 // ------------------------------------------------------------------------------------------------------
+static const u64 *cur_mask(pb_ctx *ctx);
 static int finish_count(pb_ctx *ctx, uint64_t *occ_hist, uint64_t *max_occ)
 {
     // histogram of the distinct arrays (K4a) + copy out
@@ -1105,7 +1126,7 @@ static int count_direct(pb_ctx *ctx, unsigned k)
         StageTimer tm(ctx, "count");
         if (ctx->stream_len >= k) {
             count_kernel<W><<<grid_for(ctx->stream_len, 256, gc ? atoi(gc) : 256 * 32), 256, 0, ctx->stream>>>(
-                (const u64 *)ctx->packed.p, (const u64 *)ctx->nmask.p, ctx->stream_len, k, tv, 256u, (u64 *)ctx->d_scalars.p);
+                (const u64 *)ctx->packed.p, cur_mask(ctx), ctx->stream_len, k, tv, 256u, (u64 *)ctx->d_scalars.p);
         }
         HIPCHK(hipGetLastError());
         if ((rc = tm.stop()) != PB_OK) return rc;
@@ -1172,7 +1193,7 @@ static int count_partitioned(pb_ctx *ctx, unsigned k, bool *done)
         {
             StageTimer t1(ctx, "part1");
             const u64 n_tiles = (ctx->stream_len + PB_TILE - 1) / PB_TILE;
-            part1_kernel<<<grid_for(n_tiles, 1, 256 * 4), PB_PART_THREADS, 0, ctx->stream>>>((const u64 *)ctx->packed.p, (const u64 *)ctx->nmask.p,
+            part1_kernel<<<grid_for(n_tiles, 1, 256 * 4), PB_PART_THREADS, 0, ctx->stream>>>((const u64 *)ctx->packed.p, cur_mask(ctx),
                                                                                 ctx->stream_len, (ctx->stream_len + 63) / 64 + PB_STREAM_PAD_WORDS64, k, p);
             HIPCHK(hipGetLastError());
             if ((rc = t1.stop()) != PB_OK) return rc;
@@ -1471,3 +1492,5 @@ int pb_merge_end(pb_ctx *ctx, uint64_t *occ_hist, uint64_t *max_occ, uint64_t *n
 }
 
 } // extern "C"
+
+#include "pb_graph.inc"

@@ -1,0 +1,356 @@
+// `platanus_b assemble` host driver on top of libpbgpu (include/pbgpu.h).
+//
+// Control flow, option handling, floating-point expressions and stderr progress lines follow the reference's
+// Assemble::exec / initialKmerAssemble / saveAndRedoAssemble / outputAndAfterTreatment (assemble.cpp:140-622); every
+// Counter / BruijnGraph call whose cost is per k-mer or per read window is a C-ABI call into the HIP library, the
+// ~10^4-node cleaning steps stay on the host (node_graph.hpp).  No CPU fallback: without the device the constructor fails.
+#include "assemble_gpu.hpp"
+#include "device_graph.hpp"
+#include "schedule.hpp"
+
+#include <cfloat>
+#include <climits>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <tuple>
+
+extern "C" {
+#include "../../include/pbgpu.h"
+}
+
+namespace pbh {
+
+namespace {
+
+struct GpuError : std::runtime_error {
+    int code;
+    GpuError(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+struct Driver {
+    const GpuAssembleOptions &opt;
+    pb_ctx *ctx = nullptr;
+    double min_log_p_join = 0;
+    double avg_len = 0, avg_cov = 0;
+    std::vector<unsigned> k;
+    std::vector<u64> cutoff;
+    u64 num_k = 0;
+    std::tuple<Graph<1>, Graph<2>, Graph<3>, Graph<4>, Graph<5>> graphs;       // reused across rounds (assemble.h:55-60)
+    std::vector<ContigRecord> contigs, junctions;
+    std::vector<u64> occ_hist = std::vector<u64>(PB_OCC_BINS);
+    u64 max_occ = 0;
+
+    explicit Driver(const GpuAssembleOptions &o) : opt(o)
+    {
+        const int rc = pb_create(o.device, &ctx);
+        if (rc != PB_OK) throw GpuError(rc, std::string("libpbgpu: ") + pb_last_error(nullptr));
+    }
+    ~Driver() { pb_destroy(ctx); }
+    void chk(int rc) const { if (rc != PB_OK) throw GpuError(rc, std::string("libpbgpu: ") + pb_last_error(ctx)); }
+    template <int W> Graph<W> &graph() { return std::get<W - 1>(graphs); }
+    void log(const std::string &s) const { if (opt.verbose) std::cerr << s << std::endl; }
+
+    // sortedKeyFromKmerFile + loadKmer + makeInitialBruijnGraph (assemble.cpp:343-358 / 474-478 / 613-617)
+    template <int W> void retain_and_build(unsigned kk, u64 min_occ)
+    {
+        u64 n = 0;
+        log("loading kmers...");
+        chk(pb_retain(ctx, (unsigned)min_occ, &n));
+        std::vector<u64> keys(n * W);
+        std::vector<u16> counts(n);
+        std::vector<uint8_t> adj(n);
+        std::vector<uint32_t> nbr(2 * n);
+        chk(pb_fetch_retained(ctx, keys.data(), counts.data()));
+        log("connecting kmers...");
+        chk(pb_graph_adjacency(ctx, adj.data(), nbr.data()));
+        DeviceGraphInput<W> in;
+        in.k = kk; in.n = n; in.keys = keys.data(); in.counts = counts.data(); in.adj = adj.data(); in.nbr = nbr.data();
+        Graph<W> &g = graph<W>();
+        g.set_k(kk);
+        make_initial_from_device(g, in);
+    }
+
+    // assemble.cpp:304-386
+    template <int W> void initial()
+    {
+        Graph<W> &g = graph<W>();
+        if (opt.verbose) std::cerr << "K = " << k[0] << ", saving kmers from reads..." << std::endl;
+        cutoff.clear();
+        u64 n_inst = 0, n_distinct = 0;
+        chk(pb_count(ctx, k[0], occ_hist.data(), &max_occ, &n_inst, &n_distinct));
+        const u64 llm = left_local_minimal_value(occ_hist, max_occ, 1);
+        if (!opt.repeat) cutoff.push_back(opt.n_cutoff != 0 ? opt.n_cutoff : std::max<u64>(llm / 2, 2ull));
+        else cutoff.push_back(opt.n_cutoff != 0 ? opt.n_cutoff : std::max<u64>(llm, 2ull));
+        avg_cov = dist_average(occ_hist, cutoff[0], max_occ);
+        if (opt.expected_cov != "") avg_cov = atof(opt.expected_cov.c_str());
+        std::vector<u64> len_hist(500001);
+        chk(pb_reads_length_hist(ctx, len_hist.data(), len_hist.size()));
+        avg_len = dist_average(len_hist, 0, 500000);
+        avg_cov = avg_cov * avg_len / (avg_len - k[0] + 1.0);
+        if (opt.verbose) std::cerr << "AVE_READ_LEN=" << avg_len << std::endl;
+        num_k = extend_kmer(min_log_p_join, avg_cov, avg_len, opt.min_cov, opt.max_k_ratio, k, cutoff, opt.step, opt.verbose);
+
+        std::ostringstream oss;
+        oss << opt.out_prefix << '_' << k[0] << "merFrq.tsv";
+        {
+            std::ofstream ofs(oss.str().c_str());                                  // counter.h:999-1007
+            for (u64 i = 1; i <= max_occ; ++i) ofs << i << "\t" << occ_hist[i] << std::endl;
+        }
+        if (opt.kmer_occ_only) {
+            write_kmer_occ<W>(cutoff[0]);
+            return;
+        }
+        retain_and_build<W>(k[0], cutoff[0]);
+        g.cut_branch_iterative(opt.verbose);
+        if (opt.expected_cov == "") avg_cov = g.average_coverage_excluding_bubble();
+        else avg_cov = atof(opt.expected_cov.c_str());
+        avg_cov = avg_cov * avg_len / (avg_len - k[0] + 1.0);
+    }
+
+    // PREFIX_kmer_occ.bin (counter.h:954-963, doubleHash.h:266-278).  The file holds a valid DoubleHash layout of the
+    // retained (key,count) set for the table size the reference would choose at this -m; the slot of each key follows
+    // insertion in ascending key order, NOT the reference's -t 1 first-occurrence order (CT8: byte-exact layout is
+    // produced by the oracle only).
+    template <int W> void write_kmer_occ(u64 min_occ)
+    {
+        u64 n = 0;
+        chk(pb_retain(ctx, (unsigned)min_occ, &n));
+        std::vector<u64> keys(n * W);
+        std::vector<u16> counts(n);
+        chk(pb_fetch_retained(ctx, keys.data(), counts.data()));
+        static const u64 pair_bytes[6] = {0, 16, 48, 56, 64, 72};
+        const u64 memory = opt.memory_gb * 1000000000ull;
+        long base = (long)pair_bytes[W];
+        u64 tmp = memory / base;
+        base = std::log(tmp) / std::log(2);
+        tmp = std::pow(2, base);
+        while (tmp > memory) tmp >>= 1;
+        u64 size = std::log(n / 0.9) / std::log(2);
+        size = std::pow(2, size + 1);
+        const u64 slots = std::max(size, tmp);
+        const u64 nmask = slots - 1;
+        unsigned index_len = 64;
+        for (unsigned i = 1; i < 64; ++i) if ((slots >> i) == 0) { index_len = i; break; }
+        const unsigned shifter = index_len >= 32 ? 0 : 2 * index_len;
+        std::vector<uint32_t> slot_of(slots, 0);                                 // 0 = empty, else record index + 1
+        for (u64 i = 0; i < n; ++i) {
+            u64 h = 0, st = 0;
+            for (int w = 0; w < W; ++w) {
+                const u64 v = keys[i * W + w];
+                h += v + (v >> index_len) + (v >> shifter);
+                st += ~v ^ (v >> index_len) ^ (v >> shifter);
+            }
+            h &= nmask;
+            st |= 1;
+            while (slot_of[h]) h = (h + st) & nmask;
+            slot_of[h] = (uint32_t)(i + 1);
+        }
+        FILE *f = fopen((opt.out_prefix + "_kmer_occ.bin").c_str(), "wb");
+        if (!f) throw std::runtime_error("cannot open " + opt.out_prefix + "_kmer_occ.bin");
+        const u64 kk = k[0];
+        fwrite(&kk, 8, 1, f);
+        fwrite(&nmask, 8, 1, f);
+        for (u64 s = 0; s < slots; ++s) {
+            if (!slot_of[s]) continue;
+            const u64 i = slot_of[s] - 1;
+            fwrite(&s, 8, 1, f);
+            if (W > 1) { const u64 z[3] = {0, 0, kk}; fwrite(z, 8, 3, f); }
+            fwrite(&keys[i * W], 8, W, f);
+            fwrite(&counts[i], 2, 1, f);
+        }
+        fclose(f);
+    }
+
+    // assemble.cpp:449-459 saveGraph: edge k-mers of the finished graph -> read filter on the device
+    template <int W> void save_graph(unsigned graph_k, unsigned next_k)
+    {
+        std::vector<u64> edge;
+        graph<W>().save_edge_kmers([&](const Key<W> &key, u16) { for (int w = 0; w < W; ++w) edge.push_back(key.w[w]); }, next_k);
+        log("extracting reads (containing kmer used in contig assemble)...");
+        u64 kept = 0;
+        chk(pb_reads_filter(ctx, graph_k, edge.data(), edge.size() / W, &kept));
+    }
+
+    // saveContig<NEXT> (graph.h:1655-1771): strings + values go to the device, which derives the next-k table
+    template <int WP> void contig_table(unsigned next_k, double ratio)
+    {
+        std::vector<uint8_t> bases;
+        std::vector<u64> off{0};
+        std::vector<u16> vals;
+        graph<WP>().for_each_contig_string(next_k, ratio, [&](const std::vector<unsigned char> &str, u16 occ) {
+            bases.insert(bases.end(), str.begin(), str.end());
+            off.push_back(bases.size());
+            vals.push_back(occ);
+        });
+        u64 nw = 0;
+        chk(pb_contig_table_build(ctx, next_k, bases.data(), off.data(), vals.data(), vals.size(), &nw));
+    }
+
+    // assemble.cpp:467-498 redoAssemble
+    template <int W> void redo(unsigned kk, u64 position)
+    {
+        if (opt.verbose) std::cerr << "K = " << kk << ", saving additional kmers(not found in contigs) from reads..." << std::endl;
+        u64 nd = 0;
+        chk(pb_count_considering_contigs(ctx, kk, occ_hist.data(), &max_occ, &nd));
+        if (opt.verbose) std::cerr << "COVERAGE_CUTOFF = " << cutoff[position] << std::endl;
+        retain_and_build<W>(kk, cutoff[position]);
+        graph<W>().cut_branch_iterative(opt.verbose);
+    }
+
+    // assemble.cpp:392-443
+    template <int WP, int WN> void save_and_redo(unsigned kk, unsigned prev_k, u64 position)
+    {
+        save_graph<WP>(prev_k, kk);
+        contig_table<WP>(kk, (avg_len - kk + 1.0) / (avg_len - prev_k + 1.0));
+        graph<WP>().delete_all();
+        if (opt.verbose) std::cerr << "K = " << kk << ", loading kmers from contigs..." << std::endl;
+        redo<WN>(kk, position);
+    }
+
+    // assemble.cpp:506-622
+    template <int W> void output_and_after(unsigned kk)
+    {
+        Graph<W> &g = graph<W>();
+        const u64 left_min = g.left_minimal_coverage();
+        const u64 length_cutoff = kk * 2;
+        if (opt.verbose) {
+            std::cerr << "LENGTH_CUTOFF = " << length_cutoff << std::endl;
+            std::cerr << "COVERAGE_CUTOFF = " << left_min << std::endl;
+        }
+        g.delete_erroneous_iterative(length_cutoff, left_min, opt.verbose);
+        avg_cov = avg_cov * (avg_len - kk + 1.0) / avg_len;
+        if (atoi(opt.bubble.c_str()) > 0) g.crush_bubble_iterative(avg_cov, opt.verbose);
+        // saveGraph(k, allReadFP): diff == 0, so no edge k-mer is stored and no read survives
+        chk(pb_reads_restore(ctx));
+        save_graph<W>(kk, kk);
+        contig_table<W>(kk, 1.0);
+        g.delete_all();
+        if (opt.verbose) std::cerr << "K = " << kk << ", loading kmers from contigs..." << std::endl;
+        if (opt.verbose) std::cerr << "K = " << kk << ", saving additional kmers(not found in contigs) from reads..." << std::endl;
+        u64 nd = 0;
+        chk(pb_count_considering_contigs(ctx, kk, occ_hist.data(), &max_occ, &nd));
+        retain_and_build<W>(kk, cutoff[num_k - 1]);
+        g.save_contig_simple(contigs, avg_len / (avg_len - kk + 1.0));
+        g.save_junction(junctions, avg_len / (avg_len - kk + 1.0));
+    }
+};
+
+template <typename F> void dispatch_w(unsigned k, F &&f)
+{
+    if (k <= 32) f(std::integral_constant<int, 1>());
+    else if (k <= 64) f(std::integral_constant<int, 2>());
+    else if (k <= 96) f(std::integral_constant<int, 3>());
+    else if (k <= 128) f(std::integral_constant<int, 4>());
+    else if (k <= 160) f(std::integral_constant<int, 5>());
+    else throw std::runtime_error("k > 160 is not supported by the device path");
+}
+
+// FASTA/FASTQ reader with the reference's line rules (assemble.cpp:790-986); bases are handed over as ASCII,
+// the device applies Char2Bin (common.h:256)
+void read_file(const std::string &path, std::string &bases, std::vector<u64> &off)
+{
+    FILE *fp = nullptr;
+    bool piped = false;
+    const size_t L = path.size();
+    if (L > 3 && path.compare(L - 3, 3, ".gz") == 0) { fp = popen(("gzip -cd " + path).c_str(), "r"); piped = true; }
+    else if (L > 4 && path.compare(L - 4, 4, ".bz2") == 0) { fp = popen(("bzip2 -cd " + path).c_str(), "r"); piped = true; }
+    else fp = fopen(path.c_str(), "r");
+    if (!fp) throw std::runtime_error("cannot open " + path);
+    std::string line, read;
+    char buf[1 << 16];
+    auto getline_fp = [&](std::string &out) -> bool {
+        out.clear();
+        while (fgets(buf, sizeof buf, fp)) {
+            const size_t n = strlen(buf);
+            if (n && buf[n - 1] == '\n') { out.append(buf, n - 1); return true; }
+            out.append(buf, n);
+        }
+        return !out.empty();
+    };
+    auto flush = [&]() {
+        if (read.length() >= 500000) throw std::runtime_error("Read file exception!!\nread length is too long");   // common.h:465-467
+        bases += read;
+        off.push_back(bases.size());
+        read.clear();
+    };
+    if (!getline_fp(line)) { if (piped) pclose(fp); else fclose(fp); throw std::runtime_error("empty read file " + path); }
+    const bool fastq = line[0] == '@';
+    if (!fastq && line[0] != '>') throw std::runtime_error("Read file exception!!\nRead file is not FASTA/FASTQ format.");
+    if (fastq) {
+        bool flag = true;
+        while (getline_fp(line)) {
+            if (line.length() == 0) continue;
+            if (line[0] != '@') {
+                if (flag && line[0] != '+') read += line; else flag = false;
+            } else {
+                if (read.length() != 0) flush();
+                flag = true;
+            }
+        }
+    } else {
+        while (getline_fp(line)) {
+            if (line.empty() || line[0] != '>') read += line;
+            else if (read.length() != 0) flush();
+        }
+    }
+    flush();                                               // trailing read, written even when empty
+    if (piped) pclose(fp); else fclose(fp);
+}
+
+} // namespace
+
+int run_assemble_gpu(const GpuAssembleOptions &opt)
+{
+    if (opt.repeat) throw std::runtime_error("-repeat is outside the scope of the device path (DESIGN.md section 1)");
+    Driver d(opt);
+    d.min_log_p_join = log(1.0 - pow(10.0, -opt.safety));
+    double bubble = atof(opt.bubble.c_str());
+    std::get<0>(d.graphs).set_thresholds(bubble, opt.branch);
+    std::get<1>(d.graphs).set_thresholds(bubble, opt.branch);
+    std::get<2>(d.graphs).set_thresholds(bubble, opt.branch);
+    std::get<3>(d.graphs).set_thresholds(bubble, opt.branch);
+    std::get<4>(d.graphs).set_thresholds(bubble, opt.branch);
+
+    for (const std::string &f : opt.files) {
+        std::string bases;
+        std::vector<u64> off{0};
+        read_file(f, bases, off);
+        const u64 n = off.size() - 1;
+        // hand the file over in batches of ~64 MB of bases
+        u64 lo = 0;
+        while (lo < n) {
+            u64 hi = lo;
+            while (hi < n && off[hi + 1] - off[lo] < (64ull << 20)) ++hi;
+            if (hi == lo) ++hi;
+            d.chk(pb_reads_append(d.ctx, (const uint8_t *)bases.data(), off.data() + lo, hi - lo, 1));
+            lo = hi;
+        }
+    }
+    d.k.assign(1, opt.k0);
+    dispatch_w(opt.k0, [&](auto w) { d.template initial<decltype(w)::value>(); });
+    if (opt.kmer_occ_only) {
+        if (opt.verbose) std::cerr << "assemble completed!" << std::endl;
+        return 0;
+    }
+    for (u64 i = 1; i < d.num_k; ++i) {
+        const unsigned kp = d.k[i - 1], kn = d.k[i];
+        dispatch_w(kp, [&](auto wp) {
+            dispatch_w(kn, [&](auto wn) {
+                constexpr int WP = decltype(wp)::value, WN = decltype(wn)::value;
+                if constexpr (WN >= WP) d.template save_and_redo<WP, WN>(kn, kp, i);
+            });
+        });
+    }
+    const unsigned klast = d.k[d.num_k - 1];
+    dispatch_w(klast, [&](auto w) { d.template output_and_after<decltype(w)::value>(klast); });
+    const std::string out = opt.out_prefix + "_contig.fa";
+    print_contigs(out, d.contigs, 1.0, d.avg_len, klast, "seq", false);
+    print_contigs(out, d.junctions, 1.0, d.avg_len, klast, "junction", true);
+    if (opt.verbose) std::cerr << "assemble completed!" << std::endl;
+    return 0;
+}
+
+} // namespace pbh

@@ -1,12 +1,11 @@
-// TEST INFRASTRUCTURE ONLY -- oracle restatement of `platanus_b assemble` (assemble.cpp:116-782).
+// Options of `platanus_b assemble` (defaults: assemble.cpp:55-70) + the device to run on.
 #pragma once
-#include "counter.hpp"
 #include <string>
 #include <vector>
 
-namespace pbo {
+namespace pbh {
 
-struct AssembleOptions {                 // defaults: assemble.cpp:55-70
+struct GpuAssembleOptions {
     std::string out_prefix = "out";
     std::vector<std::string> files;
     unsigned k0 = 32;
@@ -15,20 +14,16 @@ struct AssembleOptions {                 // defaults: assemble.cpp:55-70
     unsigned n_cutoff = 0;               // -n (0 = auto)
     unsigned min_cov = 1;                // -c
     double safety = 10.0;                // -a
-    std::string bubble = "0";            // -u (kept as text: atoi() decides whether the final crush runs, Q1)
+    std::string bubble = "0";            // -u (text: atoi() decides whether the final bubble crush runs)
     double branch = 0.5;                 // -d
     std::string expected_cov = "";       // -e
-    unsigned long long memory_gb = 16;   // -m
+    unsigned long long memory_gb = 16;   // -m (only sizes the table written to PREFIX_kmer_occ.bin)
     bool kmer_occ_only = false;
     bool repeat = false;
     bool verbose = true;
+    int device = 0;                      // not in the reference: which GPU
 };
 
-struct KmerSchedule {
-    std::vector<unsigned> k;
-    std::vector<u64> cutoff;
-};
+int run_assemble_gpu(const GpuAssembleOptions &opt);
 
-int run_assemble(const AssembleOptions &opt, const ReadSet &reads);
-
-} // namespace pbo
+} // namespace pbh

@@ -1,0 +1,67 @@
+// platanus_b (MI355X build): same command line as the reference's `platanus_b assemble` (main.cpp:70-149,
+// baseCommand.cpp:56-136, assemble.cpp:55-110).  Only the `assemble` command exists here.
+#include "assemble_gpu.hpp"
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+
+static void usage()
+{
+    std::cerr << "\nUsage platanus_b assemble [Options]\n"
+              << "Options:\n"
+              << "    -o STR               : prefix of output files (default out, length <= 200)\n"
+              << "    -f FILE1 [FILE2 ...] : reads file (fasta or fastq, number <= 100)\n"
+              << "    -k INT               : initial k-mer size (default 32)\n"
+              << "    -K FLOAT             : maximum-k-mer factor (maximum-k = FLOAT*read-length, default  0.5)\n"
+              << "    -s INT               : step size of k-mer extension (>= 1, default 10)\n"
+              << "    -n INT               : initial k-mer coverage cutoff (default 0, 0 means auto)\n"
+              << "    -c INT               : minimun k-mer coverage (default 1)\n"
+              << "    -a FLOAT             : k-mer extension safety level (default 10.0)\n"
+              << "    -u FLOAT             : maximum difference for bubble crush (identity, default 0)\n"
+              << "    -d FLOAT             : maximum difference for branch cutting (coverage ratio, default 0.5)\n"
+              << "    -e FLOAT             : k-mer coverage depth (k = initial k-mer size specified by -k) of homozygous region (default auto)\n"
+              << "    -t INT               : number of threads (accepted, unused: the k-mer work runs on the GPU)\n"
+              << "    -m INT               : memory limit for making kmer distribution (GB, >=1, default 16; sizes PREFIX_kmer_occ.bin only)\n"
+              << "    -tmp DIR             : directory for temporary files (accepted, unused: no temporary files)\n"
+              << "    -kmer_occ_only       : only output k-mer occurrence table (out_kmer_occ.bin; default off) \n"
+              << "    -gpu INT             : device id (default 0)\n"
+              << "\n\nOutputs:\n    PREFIX_contig.fa\n    PREFIX_kmerFrq.tsv\n\nNote, PREFIX is specified by -o\n" << std::endl;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 2 || strcmp(argv[1], "assemble") != 0) {
+        std::cerr << "Usage: platanus_b Command [options]\n\nCommand: assemble" << std::endl;
+        return 1;
+    }
+    pbh::GpuAssembleOptions o;
+    for (int i = 2; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto val = [&]() -> std::string { if (i + 1 >= argc) { usage(); exit(1); } return argv[++i]; };
+        if (a == "-o") o.out_prefix = val();
+        else if (a == "-k") o.k0 = atoi(val().c_str());
+        else if (a == "-K") o.max_k_ratio = atof(val().c_str());
+        else if (a == "-s") o.step = atoi(val().c_str());
+        else if (a == "-n") o.n_cutoff = atoi(val().c_str());
+        else if (a == "-c") o.min_cov = atoi(val().c_str());
+        else if (a == "-a") o.safety = atof(val().c_str());
+        else if (a == "-u") o.bubble = val();
+        else if (a == "-d") o.branch = atof(val().c_str());
+        else if (a == "-e") o.expected_cov = val();
+        else if (a == "-t") val();
+        else if (a == "-m") o.memory_gb = atoi(val().c_str());
+        else if (a == "-tmp") val();
+        else if (a == "-gpu") o.device = atoi(val().c_str());
+        else if (a == "-kmer_occ_only") o.kmer_occ_only = true;
+        else if (a == "-repeat") o.repeat = true;
+        else if (a == "-f") { while (i + 1 < argc && argv[i + 1][0] != '-') o.files.push_back(argv[++i]); }
+        else { usage(); return 1; }              // unknown option / -h: usage, exit 1 (main.cpp:114-117)
+    }
+    if (o.files.empty()) { usage(); return 1; }
+    try {
+        return pbh::run_assemble_gpu(o);
+    } catch (const std::exception &e) {
+        std::cerr << "Error: " << e.what() << std::endl;
+        return 2;
+    }
+}

@@ -679,9 +679,11 @@ struct Graph {
     }
 
     // graph.h:1655-1771
-    // maxput(canonical next-k key, occ): value = max(value, occ), nothing written when occ is not larger (graph.h:1762-1767)
-    template <int WN, typename MAXPUT>
-    void save_contig(unsigned next_k, double ratio, MAXPUT &&maxput)
+    // graph.h:1655-1737: for every live straight, the string [<= diff tail bases of the unique straight left of the left
+    // junction] + [left junction base] + straight + [right junction base] + [<= diff head bases ...] (left -> right, codes
+    // 0..3) and occ = (u16)(coverage * ratio + 0.5).  f(str, occ) is called for strings of at least next_k bases.
+    template <typename F>
+    void for_each_contig_string(unsigned next_k, double ratio, F &&f)
     {
         const u64 diff = next_k - k;
         std::vector<unsigned char> str;            // left -> right
@@ -721,14 +723,24 @@ struct Graph {
                 }
             }
             if (str.size() < next_k) continue;
+            const u16 occ = st->coverage * ratio + 0.5;
+            f(str, occ);
+        }
+    }
+
+    // graph.h:1738-1767 on top of the strings: maxput(canonical next-k key, occ) means value = max(value, occ), nothing
+    // written when occ is not larger
+    template <int WN, typename MAXPUT>
+    void save_contig(unsigned next_k, double ratio, MAXPUT &&maxput)
+    {
+        for_each_contig_string(next_k, ratio, [&](const std::vector<unsigned char> &str, u16 occ) {
             Kmer<WN> km(next_k);
             for (unsigned i = 0; i < next_k - 1; ++i) km.push_right(str[i]);
-            const u16 occ = st->coverage * ratio + 0.5;
             for (u64 i = next_k - 1; i < str.size(); ++i) {
                 km.push_right(str[i]);
                 maxput(km.canon(), occ);
             }
-        }
+        });
     }
 
     void save_contig_simple(std::vector<ContigRecord> &out, double ratio) const       // graph.h:1774-1796
