@@ -132,3 +132,13 @@ def extend_kmer(min_log_p_join, avg_cov, avg_len, min_cov, max_k_ratio, k0, cuto
 
 def have_reference() -> bool:
     return os.path.exists(REF_BIN) and os.access(REF_BIN, os.X_OK)
+
+
+def replay_check(codes: np.ndarray, offsets: np.ndarray, k: int, min_occ: int) -> int:
+    """0 if the product's adjacency-array DFS replay (platanus_b_amd/host/device_graph.hpp) builds exactly the node
+    tables of the oracle's k-mer-level DFS, in container order; CPU only."""
+    codes = np.ascontiguousarray(codes, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    l = lib()
+    l.pbo_replay_check.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint, C.c_uint64, C.c_void_p, C.c_void_p]
+    return l.pbo_replay_check(codes.ctypes.data, offsets.ctypes.data, offsets.size - 1, k, min_occ, None, None)

@@ -161,3 +161,99 @@ unsigned long long pbo_extend_kmer(double min_log_p_join, double avg_cov, double
 }
 
 } // extern "C"
+
+// ---- host-logic check without a GPU ---------------------------------------------------------------------------------
+// Builds the retained set with the oracle's counter, computes the adjacency arrays the device would deliver
+// (pb_graph_adjacency's contract, include/pbgpu.h) with plain CPU probes, runs the PRODUCT's DFS replay
+// (platanus_b_amd/host/device_graph.hpp) and the oracle's k-mer-level DFS on the same set, and compares the two node
+// tables in container iteration order.  Returns 0 when identical, a positive code for the first difference.
+#include "graph.hpp"
+#include "../../platanus_b_amd/host/device_graph.hpp"
+
+namespace {
+template <int W>
+int replay_check(const ReadSet &rs, unsigned k, u64 min_occ)
+{
+    Counter<W> c;
+    const u64 dh = c.count_reads(k, rs, 1000000000ull);
+    std::vector<Key<W>> sorted = c.sorted_keys(min_occ);
+    // counts in sorted order + CPU adjacency
+    std::vector<std::pair<Key<W>, u16>> kv;
+    for (size_t i = 0; i < c.kmer_keys.size(); ++i) if (c.kmer_vals[i] >= min_occ) kv.push_back({c.kmer_keys[i], c.kmer_vals[i]});
+    std::sort(kv.begin(), kv.end(), [](const std::pair<Key<W>, u16> &a, const std::pair<Key<W>, u16> &b) { return a.first < b.first; });
+    const u64 n = kv.size();
+    std::vector<u64> keys(n * W);
+    std::vector<u16> counts(n);
+    for (u64 i = 0; i < n; ++i) { for (int w = 0; w < W; ++w) keys[i * W + w] = kv[i].first.w[w]; counts[i] = kv[i].second; }
+    c.load_kmers(min_occ, dh);
+    Graph<W> ref;
+    ref.set_k(k);
+    ref.make_initial(c.table, sorted);
+
+    auto find_idx = [&](const Key<W> &canon) -> long {
+        auto it = std::lower_bound(kv.begin(), kv.end(), canon, [](const std::pair<Key<W>, u16> &a, const Key<W> &b) { return a.first < b; });
+        return (it != kv.end() && it->first == canon) ? (long)(it - kv.begin()) : -1;
+    };
+    std::vector<uint8_t> adj(n);
+    std::vector<uint32_t> nbr(2 * n, 0xFFFFFFFFu);
+    Graph<W> tmp;
+    tmp.set_k(k);
+    for (u64 i = 0; i < n; ++i) {
+        unsigned rf = 0, lf = 0;
+        uint32_t rn = 0xFFFFFFFFu, ln = 0xFFFFFFFFu;
+        for (unsigned b = 0; b < 4; ++b) {
+            for (int side = 0; side < 2; ++side) {
+                const Key<W> s = side == 0 ? tmp.succ(kv[i].first, b) : tmp.pred(kv[i].first, b);
+                const Key<W> r = revcomp(s, k);
+                const bool flip = r < s;
+                const long j = find_idx(flip ? r : s);
+                if (j < 0) continue;
+                if (side == 0) { rf |= 1u << b; rn = ((uint32_t)j << 1) | (flip ? 1u : 0u); }
+                else { lf |= 1u << b; ln = ((uint32_t)j << 1) | (flip ? 1u : 0u); }
+            }
+        }
+        adj[i] = (uint8_t)((lf << 4) | rf);
+        if (flag_count(rf) == 1) nbr[2 * i] = rn;
+        if (flag_count(lf) == 1) nbr[2 * i + 1] = ln;
+    }
+    DeviceGraphInput<W> in;
+    in.k = k; in.n = n; in.keys = keys.data(); in.counts = counts.data(); in.adj = adj.data(); in.nbr = nbr.data();
+    Graph<W> got;
+    got.set_k(k);
+    make_initial_from_device(got, in);
+
+    if (got.left.size() != ref.left.size()) return 1;
+    if (got.junctions.size() != ref.junctions.size()) return 2;
+    auto a = got.left.begin();
+    for (auto b = ref.left.begin(); b != ref.left.end(); ++a, ++b) {
+        if (!(a->first == b->first)) return 3;
+        if (a->second.length != b->second.length || a->second.coverage != b->second.coverage || a->second.out != b->second.out) return 4;
+        if (a->second.seq != b->second.seq) return 5;
+    }
+    auto ja = got.junctions.begin();
+    for (auto jb = ref.junctions.begin(); jb != ref.junctions.end(); ++ja, ++jb) {
+        if (!(ja->first == jb->first)) return 6;
+        if (ja->second.coverage != jb->second.coverage || ja->second.out != jb->second.out) return 7;
+    }
+    return 0;
+}
+} // namespace
+
+extern "C" int pbo_replay_check(const uint8_t *codes, const unsigned long long *off, unsigned long long n_reads, unsigned k,
+                                unsigned long long min_occ, unsigned long long *n_straight, unsigned long long *n_junction)
+{
+    ReadSet rs;
+    rs.bases.assign(codes + off[0], codes + off[n_reads]);
+    rs.off.resize(n_reads + 1);
+    for (u64 i = 0; i <= n_reads; ++i) rs.off[i] = off[i] - off[0];
+    (void)n_straight; (void)n_junction;
+    try {
+        switch (words_for_k(k)) {
+        case 1: return replay_check<1>(rs, k, min_occ);
+        case 2: return replay_check<2>(rs, k, min_occ);
+        case 3: return replay_check<3>(rs, k, min_occ);
+        case 4: return replay_check<4>(rs, k, min_occ);
+        default: return replay_check<5>(rs, k, min_occ);
+        }
+    } catch (...) { return -1; }
+}
