@@ -107,6 +107,19 @@ int pb_merge_end(pb_ctx *ctx, uint64_t *occ_hist, uint64_t *max_occ, uint64_t *n
  * array steps instead of hash probes; see platanus_b_amd/host/device_graph.hpp. */
 int pb_graph_adjacency(pb_ctx *ctx, uint8_t *adj, uint32_t *nbr);
 
+/* K7 chain compaction (the unitig walk of graph.h:406-542 as node-parallel kernels: pointer-jumping list ranking over
+ * the adjacency arrays, per-chain coverage sum, sequence gather).  Call after pb_graph_adjacency.
+ *   chain_of[n]  chain id of k-mer i | 0xFFFFFFFF junction k-mer | 0xFFFFFFFE k-mer on a cycle / hairpin / self loop
+ *                (the host walks those k-mer by k-mer with the reference's "visited" rule)
+ *   orient[n]    1 if k-mer i is traversed as its reverse complement when the chain is read from end A to end B
+ *   per chain c: len[c] k-mers, sum[c] = sum of their counts, end_a[c] / end_b[c] = (k-mer index << 1) | traversed-as-revcomp
+ *                of the first / last k-mer, seq_woff[c] = first word of its packed sequence in seq[] (A -> B string of
+ *                len+k-1 bases in Straight::seq layout: position p counts from the B end, 32 positions per word)
+ * Chain numbering is arbitrary (it does not reach any output: the host replays the reference's DFS order). */
+int pb_graph_chains(pb_ctx *ctx, uint64_t *n_chains, uint64_t *seq_words);
+int pb_graph_fetch_chains(pb_ctx *ctx, uint32_t *chain_of, uint8_t *orient, uint32_t *len, uint64_t *sum, uint32_t *end_a,
+                          uint32_t *end_b, uint64_t *seq_woff, uint64_t *seq);
+
 /* ---- multi-k rounds (assemble.cpp:392-498) ------------------------------------------------------------------- */
 /* saveEdgeKmer + pickupReadMatchedEdgeKmer (graph.h:1877-1939, counter.h:869-910): keep a read iff one of its N-free
  * k-mers (k = the finished graph's k) is among edge_keys[n_edge*W] (canonical).  Cumulative like the reference's readFP:

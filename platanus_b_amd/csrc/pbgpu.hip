@@ -70,6 +70,9 @@ struct pb_ctx {
     DevBuf contig_packed, contig_mask, ctable;   // contig-derived next-k table (saveContig)
     u64 ctable_cap = 0;
     unsigned ctable_k = 0;
+    DevBuf chain_work, chain_rec, chain_seq;     // K7 chain compaction
+    u64 n_chains = 0, chain_seq_words = 0;
+    void *chain_ptrs[2] = {nullptr, nullptr};
 
     // scratch
     DevBuf scratch[6];
@@ -957,6 +960,7 @@ void pb_destroy(pb_ctx *ctx)
     release(ctx->dist_keys); release(ctx->dist_counts); release(ctx->part_bucket1); release(ctx->part_bucket2); release(ctx->part_meta); release(ctx->part_out_counts); release(ctx->part_segs);
     release(ctx->index_table); release(ctx->nmask_cur); release(ctx->alive); release(ctx->d_read_start);
     release(ctx->contig_packed); release(ctx->contig_mask); release(ctx->ctable);
+    release(ctx->chain_work); release(ctx->chain_rec); release(ctx->chain_seq);
     for (auto &s : ctx->scratch) release(s);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);

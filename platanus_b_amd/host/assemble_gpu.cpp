@@ -9,6 +9,8 @@
 #include "schedule.hpp"
 
 #include <cfloat>
+#include <chrono>
+#include <map>
 #include <climits>
 #include <cmath>
 #include <cstdlib>
@@ -28,6 +30,19 @@ namespace {
 struct GpuError : std::runtime_error {
     int code;
     GpuError(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+struct StageClock {
+    std::map<std::string, double> acc;
+    std::vector<std::string> order;
+    void add(const std::string &name, double s) { if (!acc.count(name)) order.push_back(name); acc[name] += s; }
+};
+static StageClock g_clock;
+struct Tick {
+    std::string name;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    explicit Tick(const std::string &n) : name(n) {}
+    ~Tick() { g_clock.add(name, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count()); }
 };
 
 struct Driver {
@@ -58,19 +73,46 @@ struct Driver {
     {
         u64 n = 0;
         log("loading kmers...");
-        chk(pb_retain(ctx, (unsigned)min_occ, &n));
-        std::vector<u64> keys(n * W);
-        std::vector<u16> counts(n);
-        std::vector<uint8_t> adj(n);
-        std::vector<uint32_t> nbr(2 * n);
-        chk(pb_fetch_retained(ctx, keys.data(), counts.data()));
-        log("connecting kmers...");
-        chk(pb_graph_adjacency(ctx, adj.data(), nbr.data()));
+        std::vector<u64> keys;
+        std::vector<u16> counts;
+        std::vector<uint8_t> adj;
+        std::vector<uint32_t> nbr;
+        {
+            Tick t("retain+sort (device)");
+            chk(pb_retain(ctx, (unsigned)min_occ, &n));
+        }
+        {
+            Tick t("fetch retained + adjacency (device + D2H)");
+            keys.resize(n * W); counts.resize(n); adj.resize(n); nbr.resize(2 * n);
+            chk(pb_fetch_retained(ctx, keys.data(), counts.data()));
+            log("connecting kmers...");
+            chk(pb_graph_adjacency(ctx, adj.data(), nbr.data()));
+        }
         DeviceGraphInput<W> in;
         in.k = kk; in.n = n; in.keys = keys.data(); in.counts = counts.data(); in.adj = adj.data(); in.nbr = nbr.data();
         Graph<W> &g = graph<W>();
         g.set_k(kk);
-        make_initial_from_device(g, in);
+        if (getenv("PB_NO_CHAINS")) {                 // development switch: k-mer-level replay of the DFS
+            Tick t("DFS replay, k-mer level (host)");
+            make_initial_from_device(g, in);
+            return;
+        }
+        std::vector<uint32_t> chain_of(n), ch_len, ch_end_a, ch_end_b;
+        std::vector<uint8_t> orient(n);
+        std::vector<u64> ch_sum, ch_woff, ch_seq;
+        ChainSet cs;
+        {
+            Tick t("chain compaction (device + D2H)");
+            u64 nc = 0, words = 0;
+            chk(pb_graph_chains(ctx, &nc, &words));
+            ch_len.resize(nc); ch_end_a.resize(nc); ch_end_b.resize(nc); ch_sum.resize(nc); ch_woff.resize(nc); ch_seq.resize(words);
+            chk(pb_graph_fetch_chains(ctx, chain_of.data(), orient.data(), ch_len.data(), ch_sum.data(), ch_end_a.data(), ch_end_b.data(),
+                                      ch_woff.data(), ch_seq.data()));
+            cs.n_chains = nc; cs.chain_of = chain_of.data(); cs.orient = orient.data(); cs.len = ch_len.data(); cs.sum = ch_sum.data();
+            cs.end_a = ch_end_a.data(); cs.end_b = ch_end_b.data(); cs.seq_woff = ch_woff.data(); cs.seq = ch_seq.data();
+        }
+        Tick t("DFS replay, chain level (host)");
+        make_initial_from_chains(g, in, cs);
     }
 
     // assemble.cpp:304-386
@@ -80,7 +122,10 @@ struct Driver {
         if (opt.verbose) std::cerr << "K = " << k[0] << ", saving kmers from reads..." << std::endl;
         cutoff.clear();
         u64 n_inst = 0, n_distinct = 0;
-        chk(pb_count(ctx, k[0], occ_hist.data(), &max_occ, &n_inst, &n_distinct));
+        {
+            Tick t("count k0 (device)");
+            chk(pb_count(ctx, k[0], occ_hist.data(), &max_occ, &n_inst, &n_distinct));
+        }
         const u64 llm = left_local_minimal_value(occ_hist, max_occ, 1);
         if (!opt.repeat) cutoff.push_back(opt.n_cutoff != 0 ? opt.n_cutoff : std::max<u64>(llm / 2, 2ull));
         else cutoff.push_back(opt.n_cutoff != 0 ? opt.n_cutoff : std::max<u64>(llm, 2ull));
@@ -104,7 +149,10 @@ struct Driver {
             return;
         }
         retain_and_build<W>(k[0], cutoff[0]);
-        g.cut_branch_iterative(opt.verbose);
+        {
+            Tick t("node cleaning (host)");
+            g.cut_branch_iterative(opt.verbose);
+        }
         if (opt.expected_cov == "") avg_cov = g.average_coverage_excluding_bubble();
         else avg_cov = atof(opt.expected_cov.c_str());
         avg_cov = avg_cov * avg_len / (avg_len - k[0] + 1.0);
@@ -171,6 +219,7 @@ struct Driver {
         graph<W>().save_edge_kmers([&](const Key<W> &key, u16) { for (int w = 0; w < W; ++w) edge.push_back(key.w[w]); }, next_k);
         log("extracting reads (containing kmer used in contig assemble)...");
         u64 kept = 0;
+        Tick t("read filter (device)");
         chk(pb_reads_filter(ctx, graph_k, edge.data(), edge.size() / W, &kept));
     }
 
@@ -186,6 +235,7 @@ struct Driver {
             vals.push_back(occ);
         });
         u64 nw = 0;
+        Tick t("contig table (host strings + device)");
         chk(pb_contig_table_build(ctx, next_k, bases.data(), off.data(), vals.data(), vals.size(), &nw));
     }
 
@@ -194,9 +244,13 @@ struct Driver {
     {
         if (opt.verbose) std::cerr << "K = " << kk << ", saving additional kmers(not found in contigs) from reads..." << std::endl;
         u64 nd = 0;
-        chk(pb_count_considering_contigs(ctx, kk, occ_hist.data(), &max_occ, &nd));
+        {
+            Tick t("count missing k-mers (device)");
+            chk(pb_count_considering_contigs(ctx, kk, occ_hist.data(), &max_occ, &nd));
+        }
         if (opt.verbose) std::cerr << "COVERAGE_CUTOFF = " << cutoff[position] << std::endl;
         retain_and_build<W>(kk, cutoff[position]);
+        Tick t("node cleaning (host)");
         graph<W>().cut_branch_iterative(opt.verbose);
     }
 
@@ -314,7 +368,9 @@ int run_assemble_gpu(const GpuAssembleOptions &opt)
     std::get<3>(d.graphs).set_thresholds(bubble, opt.branch);
     std::get<4>(d.graphs).set_thresholds(bubble, opt.branch);
 
+    const auto t_start = std::chrono::steady_clock::now();
     for (const std::string &f : opt.files) {
+        Tick t("read files + upload/pack");
         std::string bases;
         std::vector<u64> off{0};
         read_file(f, bases, off);
@@ -347,9 +403,17 @@ int run_assemble_gpu(const GpuAssembleOptions &opt)
     const unsigned klast = d.k[d.num_k - 1];
     dispatch_w(klast, [&](auto w) { d.template output_and_after<decltype(w)::value>(klast); });
     const std::string out = opt.out_prefix + "_contig.fa";
-    print_contigs(out, d.contigs, 1.0, d.avg_len, klast, "seq", false);
-    print_contigs(out, d.junctions, 1.0, d.avg_len, klast, "junction", true);
+    {
+        Tick t("write contigs");
+        print_contigs(out, d.contigs, 1.0, d.avg_len, klast, "seq", false);
+        print_contigs(out, d.junctions, 1.0, d.avg_len, klast, "junction", true);
+    }
     if (opt.verbose) std::cerr << "assemble completed!" << std::endl;
+    if (getenv("PB_TIMING")) {
+        std::cerr << "\n#### STAGE WALL TIMES (s) ####" << std::endl;
+        for (const std::string &n : g_clock.order) std::cerr << n << "\t" << g_clock.acc[n] << std::endl;
+        std::cerr << "total\t" << std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() << std::endl;
+    }
     return 0;
 }
 

@@ -179,4 +179,162 @@ void make_initial_from_device(Graph<W> &gr, const DeviceGraphInput<W> &in)
     }
 }
 
+
+// ---- chain-level replay --------------------------------------------------------------------------------------------
+// With pb_graph_chains the device has already walked every simple chain (list ranking), summed its counts and gathered
+// its sequence, so the replay touches one record per node instead of one per k-mer.  A simple chain is consumed whole by
+// whichever of its k-mers the DFS reaches first (nothing inside it can be "visited" earlier, and both of its ends stop at
+// a junction or at nothing), so "visited" is kept per chain; only the strand depends on the entry k-mer.  K-mers on
+// cycles / hairpins / self loops (chain_of == 0xFFFFFFFE) are still walked one by one exactly as above.
+struct ChainSet {
+    u64 n_chains = 0;
+    const uint32_t *chain_of = nullptr;   // n
+    const uint8_t *orient = nullptr;      // n
+    const uint32_t *len = nullptr;        // per chain ...
+    const u64 *sum = nullptr;
+    const uint32_t *end_a = nullptr, *end_b = nullptr;
+    const u64 *seq_woff = nullptr;
+    const u64 *seq = nullptr;
+};
+static const uint32_t CHAIN_JUNCTION = 0xFFFFFFFFu, CHAIN_COMPLEX = 0xFFFFFFFEu;
+
+// reverse complement of a packed 2-bit string of `len` symbols (position 0 in the low bits of word 0)
+inline void revcomp_packed(const u64 *src, u64 len, std::vector<u64> &dst)
+{
+    const u64 nw = (len + 31) / 32;
+    dst.assign(nw, 0);
+    // symbol p of dst = 3 - symbol (len-1-p) of src: reverse whole words, then shift out the padding
+    std::vector<u64> tmp(nw + 1, 0);
+    for (u64 i = 0; i < nw; ++i) tmp[i] = revcom_u64(src[nw - 1 - i]);     // now the string sits in the TOP of the nw-word block
+    const unsigned pad = (unsigned)((nw * 32 - len) * 2);                   // bits to shift down
+    if (pad == 0) { for (u64 i = 0; i < nw; ++i) dst[i] = tmp[i]; }
+    else { for (u64 i = 0; i < nw; ++i) dst[i] = (tmp[i] >> pad) | (tmp[i + 1] << (64 - pad)); }
+    // revcom_u64 complemented the padding bits of the source's top word too; they are shifted out above
+    if (len & 31) dst[nw - 1] &= (1ull << (2 * (len & 31))) - 1;
+}
+
+template <int W>
+void make_initial_from_chains(Graph<W> &gr, const DeviceGraphInput<W> &in, const ChainSet &cs)
+{
+    typedef Key<W> K;
+    const unsigned k = in.k;
+    gr.junctions.clear();
+    gr.left.clear();
+    gr.right.clear();
+    std::vector<uint8_t> visited(in.n, 0);              // junction / complex k-mers
+    std::vector<uint8_t> chain_done(cs.n_chains, 0);
+    auto is_visited = [&](u64 i) -> bool {
+        const uint32_t c = cs.chain_of[i];
+        return c < CHAIN_COMPLEX ? chain_done[c] != 0 : visited[i] != 0;
+    };
+    struct Ori { u64 i; unsigned f; };
+    std::vector<Ori> stack;
+    std::vector<unsigned char> lseq, rseq;
+    std::vector<u64> rc_buf;
+    for (u64 root = 0; root < in.n; ++root) {
+        if (is_visited(root)) continue;
+        stack.clear();
+        stack.push_back({root, 0u});
+        while (!stack.empty()) {
+            const Ori s = stack.back();
+            stack.pop_back();
+            if (is_visited(s.i)) continue;
+            const uint32_t c = cs.chain_of[s.i];
+            if (c < CHAIN_COMPLEX) {
+                // ---- a whole simple chain becomes one Straight ----
+                chain_done[c] = 1;
+                const bool aligned = cs.orient[s.i] == s.f;          // entry k-mer points along A -> B
+                const u64 len = cs.len[c], ls = len + k - 1;
+                Ori ea{cs.end_a[c] >> 1, cs.end_a[c] & 1u}, eb{cs.end_b[c] >> 1, cs.end_b[c] & 1u};
+                const Ori le = aligned ? ea : Ori{eb.i, eb.f ^ 1u};
+                const Ori re = aligned ? eb : Ori{ea.i, ea.f ^ 1u};
+                const unsigned lfl = in.lflags(le.i, le.f), rfl = in.rflags(re.i, re.f);
+                if (lfl != 0) { Ori v; in.left_of(le.i, le.f, v.i, v.f); stack.push_back(v); }
+                if (rfl != 0) { Ori v; in.right_of(re.i, re.f, v.i, v.f); stack.push_back(v); }
+                Straight st;
+                st.length = len;
+                const u64 nw = (ls + 31) / 32;
+                const u64 *src = cs.seq + cs.seq_woff[c];
+                if (aligned) st.seq.assign(src, src + nw);
+                else { revcomp_packed(src, ls, rc_buf); st.seq = rc_buf; }
+                st.seq.resize((len + k + 31) / 32, 0);                // binstr_t(length + k) word count (graph.h:559)
+                st.coverage = (u16)(static_cast<double>(cs.sum[c]) / static_cast<double>(len) + 0.5);
+                st.out = (uint8_t)((lfl << 4) | rfl);
+                gr.insert_straight(st);
+                continue;
+            }
+            visited[s.i] = 1;
+            u64 sum = in.counts[s.i];
+            unsigned lfl = in.lflags(s.i, s.f), rfl = in.rflags(s.i, s.f);
+            const K start = in.oriented(s.i, s.f);
+            if (c == CHAIN_JUNCTION) {                                            // graph.h:383-404
+                for (unsigned b = 0; b < 4; ++b) {
+                    Ori o;
+                    if (rfl & (1u << b)) { in.locate(gr.succ(start, b), o.i, o.f); stack.push_back(o); }
+                    if (lfl & (1u << b)) { in.locate(gr.pred(start, b), o.i, o.f); stack.push_back(o); }
+                }
+                Junction j;
+                j.coverage = (u16)sum;
+                j.out = (uint8_t)((lfl << 4) | rfl);
+                gr.junctions[start] = j;
+                continue;
+            }
+            // ---- k-mer on a cycle / hairpin / self loop: the reference's walk, k-mer by k-mer ----
+            lseq.clear();
+            rseq.clear();
+            if (lfl) lseq.push_back((unsigned char)flag2base(lfl));
+            if (rfl) rseq.push_back((unsigned char)flag2base(rfl));
+            Ori rstop = s, lstop = s;
+            if (!rseq.empty()) {
+                Ori v;
+                in.right_of(s.i, s.f, v.i, v.f);
+                while (true) {
+                    rstop = v;
+                    if (flag_count(in.lflags(v.i, v.f)) > 1 || is_visited(v.i)) { rfl = 1u << rseq.back(); rseq.pop_back(); break; }
+                    const unsigned vr = in.rflags(v.i, v.f);
+                    if (vr == 0) { rfl = 0; sum += in.counts[v.i]; visited[v.i] = 1; break; }
+                    else if (flag_count(vr) > 1) { rfl = 1u << rseq.back(); rseq.pop_back(); break; }
+                    rfl = vr;
+                    rseq.push_back((unsigned char)flag2base(vr));
+                    sum += in.counts[v.i];
+                    visited[v.i] = 1;
+                    Ori nx;
+                    in.right_of(v.i, v.f, nx.i, nx.f);
+                    v = nx;
+                }
+            }
+            if (!lseq.empty()) {
+                Ori v;
+                in.left_of(s.i, s.f, v.i, v.f);
+                while (true) {
+                    lstop = v;
+                    if (flag_count(in.rflags(v.i, v.f)) > 1 || is_visited(v.i)) { lfl = 1u << lseq.back(); lseq.pop_back(); break; }
+                    const unsigned vl = in.lflags(v.i, v.f);
+                    if (vl == 0) { lfl = 0; sum += in.counts[v.i]; visited[v.i] = 1; break; }
+                    else if (flag_count(vl) > 1) { lfl = 1u << lseq.back(); lseq.pop_back(); break; }
+                    lfl = vl;
+                    lseq.push_back((unsigned char)flag2base(vl));
+                    sum += in.counts[v.i];
+                    visited[v.i] = 1;
+                    Ori nx;
+                    in.left_of(v.i, v.f, nx.i, nx.f);
+                    v = nx;
+                }
+            }
+            if (lfl != 0) stack.push_back(lstop);
+            if (rfl != 0) stack.push_back(rstop);
+            Straight st;
+            st.length = lseq.size() + rseq.size() + 1;
+            st.seq.assign((st.length + k + 31) / 32, 0);
+            const u64 rn = rseq.size();
+            for (u64 j = 0; j < rn; ++j) st.set(rn - 1 - j, rseq[j]);
+            for (unsigned j = 0; j < k; ++j) st.set(rn + j, start.get(j));
+            for (u64 j = 0; j < lseq.size(); ++j) st.set(rn + k + j, lseq[j]);
+            st.coverage = (u16)(static_cast<double>(sum) / static_cast<double>(st.length) + 0.5);
+            st.out = (uint8_t)((lfl << 4) | rfl);
+            gr.insert_straight(st);
+        }
+    }
+}
+
 } // namespace pbh
