@@ -243,3 +243,37 @@ def test_partitioned_path_heavy_hitter_goes_through_fallback(gpu, oracle_built, 
     g.retain(2)
     gk, gc = g.fetch_retained()
     assert np.array_equal(gk, ok) and np.array_equal(gc, ocn)
+
+
+def test_exchange_and_merge_over_rccl_single_rank(gpu, oracle_built):
+    """The multi-GPU step (export by owner -> all_to_all over RCCL -> owner merge -> histogram all-reduce) on a real
+    device with world_size 1: every record travels through torch.distributed (backend nccl = RCCL) and must come back
+    unchanged; k = 32 (1 word) and k = 45 (2 words)."""
+    import torch
+    import torch.distributed as dist
+    from platanus_b_amd import synth
+    from platanus_b_amd.multigpu import exchange_and_merge
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29577")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        r1, r2 = synth.make_reads(30_000, 40, seed=8, n_rate=0.001)
+        codes = np.concatenate([r1, r2])
+        n, L = codes.shape
+        off = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
+        for k in (32, 45):
+            oc = _oracle(codes, off, k, oracle_built)
+            ohist, omax = oc.occ_hist()
+            g = gpu(0)
+            g.reads_append_matrix(codes)
+            g.make_kmer_read_distribution(k)
+            ghist = exchange_and_merge(g, dist, 1, 0)
+            assert np.array_equal(ghist, ohist) and g.max_occ == omax
+            assert g.n_distinct == int(ohist.sum())
+            ok, ocn = oc.retain(2)
+            g.retain(2)
+            gk, gc = g.fetch_retained()
+            assert np.array_equal(gk, ok) and np.array_equal(gc, ocn)
+    finally:
+        dist.destroy_process_group()
