@@ -136,6 +136,16 @@ int pb_contig_table_build(pb_ctx *ctx, unsigned k, const uint8_t *bases, const u
  * Afterwards pb_retain / pb_fetch_* / pb_graph_adjacency work on that set. */
 int pb_count_considering_contigs(pb_ctx *ctx, unsigned k, uint64_t *occ_hist, uint64_t *max_occ, uint64_t *n_distinct);
 
+/* ---- CT8: loadKmer + outputOccurrenceTableBinary (counter.h:599-640,954-963; doubleHash.h:266-278), k <= 32 ------- */
+/* Reproduces the slot every retained k-mer occupies in the reference's final table at -t 1: first-occurrence order into
+ * the 1024 stripe tables of dh_size/1024 slots with the 32(+)-probe spill passes (counter.h:340-364,458-476), stripe-major
+ * dump order, then insertion of the k-mers with count >= min_occ into a table of max(need, dh_size) slots.
+ * dh_size = the value makeKmerReadDistributionMT returns for the run's -m (a power of two; host arithmetic, counter.h:300-309).
+ * Outputs: *table_size (the header writes table_size-1), *n_records; pb_kmer_occ_fetch copies the records in ascending
+ * slot order (exactly what writeTable() emits): slots[n], keys[n], counts[n]. */
+int pb_kmer_occ_layout(pb_ctx *ctx, uint64_t dh_size, unsigned min_occ, uint64_t *table_size, uint64_t *n_records);
+int pb_kmer_occ_fetch(pb_ctx *ctx, uint64_t *slots, uint64_t *keys, uint16_t *counts);
+
 /* ---- timing of the last call, measured with HIP events on the library's stream ------------------------- */
 /* stage names: "pack", "count", "hist", "compact", "sort", "adjacency", ... ; returns PB_EINVAL if unknown */
 int pb_last_kernel_ms(const pb_ctx *ctx, const char *stage, float *ms);

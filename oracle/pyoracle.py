@@ -44,7 +44,7 @@ def lib() -> C.CDLL:
         l.pbo_fetch_retained.argtypes = [vp, vp, vp]
         l.pbo_write_table_binary.argtypes = [vp, C.c_uint64, C.c_char_p]
         l.pbo_write_occ_distribution.argtypes = [vp, C.c_char_p]
-        l.pbo_assemble.argtypes = [vp, vp, C.c_uint64, C.c_char_p, C.c_uint, C.c_uint, C.c_uint, C.c_uint64, C.c_int, C.c_int]
+        l.pbo_assemble.argtypes = [vp, vp, C.c_uint64, C.c_char_p, C.c_uint, C.c_uint, C.c_uint, C.c_uint64, C.c_int, C.c_int, C.c_char_p]
         l.pbo_extend_kmer.argtypes = [C.c_double, C.c_double, C.c_double, C.c_uint64, C.c_double, C.c_uint, C.c_uint64,
                                       C.c_uint64, vp, vp, C.c_uint]
         l.pbo_extend_kmer.restype = C.c_uint64
@@ -115,11 +115,11 @@ class OracleCounter:
 
 
 def assemble(codes: np.ndarray, offsets: np.ndarray, out_prefix: str, k0: int = 32, step: int = 10, n_cutoff: int = 0,
-             memory_gb: int = 1, kmer_occ_only: bool = False, verbose: bool = False) -> int:
+             memory_gb: int = 1, kmer_occ_only: bool = False, verbose: bool = False, bubble: str = "") -> int:
     codes = np.ascontiguousarray(codes, dtype=np.uint8)
     offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
     return lib().pbo_assemble(codes.ctypes.data, offsets.ctypes.data, offsets.size - 1, out_prefix.encode(), k0, step,
-                              n_cutoff, memory_gb, int(kmer_occ_only), int(verbose))
+                              n_cutoff, memory_gb, int(kmer_occ_only), int(verbose), bubble.encode())
 
 
 def extend_kmer(min_log_p_join, avg_cov, avg_len, min_cov, max_k_ratio, k0, cutoff0, step):

@@ -150,8 +150,10 @@ struct Run {
         }
         g.delete_erroneous_iterative(length_cutoff, left_min, opt.verbose);
         avg_cov = avg_cov * (avg_len - kk + 1.0) / avg_len;
-        if (atoi(opt.bubble.c_str()) > 0) {
-            g.crush_bubble_iterative(avg_cov, opt.verbose);     // PREFIX_contigBubble.fa not restated
+        if (atoi(opt.bubble.c_str()) > 0) {                     // assemble.cpp:520-526 (Q1: only -u >= 1 gets here)
+            if (opt.verbose) std::cerr << "AVE_KMER_COV_REMOVING_BUBBLE=" << avg_cov << std::endl;
+            g.crush_bubble_iterative(avg_cov, opt.verbose);
+            print_bubbles(opt.out_prefix + "_contigBubble.fa", g.bubbles, avg_len / (avg_len - kk + 1.0));
         }
         save_graph<W>(kk, all_reads);          // diff == 0: inserts nothing, keeps no read
         if (W > 1) dh_size = table_size_for_memory(memory, W);

@@ -136,7 +136,7 @@ int pbo_write_occ_distribution(void *p, const char *path)
 
 // whole pipeline on in-memory reads; argv-style options as for `platanus_b assemble`
 int pbo_assemble(const uint8_t *codes, const unsigned long long *off, unsigned long long n_reads, const char *out_prefix,
-                 unsigned k0, unsigned step, unsigned n_cutoff, unsigned long long memory_gb, int kmer_occ_only, int verbose)
+                 unsigned k0, unsigned step, unsigned n_cutoff, unsigned long long memory_gb, int kmer_occ_only, int verbose, const char *bubble)
 {
     ReadSet rs;
     rs.bases.assign(codes + off[0], codes + off[n_reads]);
@@ -145,6 +145,7 @@ int pbo_assemble(const uint8_t *codes, const unsigned long long *off, unsigned l
     AssembleOptions o;
     o.out_prefix = out_prefix; o.k0 = k0; o.step = step; o.n_cutoff = n_cutoff; o.memory_gb = memory_gb;
     o.kmer_occ_only = kmer_occ_only != 0; o.verbose = verbose != 0;
+    if (bubble && *bubble) o.bubble = bubble;
     try { return run_assemble(o, rs); } catch (const std::exception &e) { fprintf(stderr, "oracle: %s\n", e.what()); return -1; }
 }
 

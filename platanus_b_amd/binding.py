@@ -66,6 +66,8 @@ def load_library() -> C.CDLL:
     lib.pb_merge_begin.argtypes = [vp, C.c_uint, C.c_uint64]
     lib.pb_merge_add.argtypes = [vp, vp, vp, C.c_uint64]
     lib.pb_merge_end.argtypes = [vp, vp, u64p, u64p]
+    lib.pb_kmer_occ_layout.argtypes = [vp, C.c_uint64, C.c_uint, u64p, u64p]
+    lib.pb_kmer_occ_fetch.argtypes = [vp, vp, vp, vp]
     _lib = lib
     return lib
 
@@ -200,6 +202,22 @@ class GpuCounter:
         n = C.c_uint64()
         self._chk(self.lib.pb_fetch_all(self.h, keys.ctypes.data, counts.ctypes.data, cap, C.byref(n)))
         return keys[:n.value], counts[:n.value]
+
+    # counter.h:155 + 161: loadKmer + outputOccurrenceTableBinary with the reference's -t 1 slot layout (k <= 32)
+    def output_occurrence_table_binary(self, path: str, min_occ: int, dh_size: int):
+        ts, nr = C.c_uint64(), C.c_uint64()
+        self._chk(self.lib.pb_kmer_occ_layout(self.h, dh_size, min_occ, C.byref(ts), C.byref(nr)))
+        n = nr.value
+        slots = np.zeros(n, dtype=np.uint64)
+        keys = np.zeros(n, dtype=np.uint64)
+        counts = np.zeros(n, dtype=np.uint16)
+        self._chk(self.lib.pb_kmer_occ_fetch(self.h, slots.ctypes.data, keys.ctypes.data, counts.ctypes.data))
+        rec = np.zeros(n, dtype=np.dtype([("slot", "<u8"), ("key", "<u8"), ("count", "<u2")]))
+        rec["slot"], rec["key"], rec["count"] = slots, keys, counts
+        with open(path, "wb") as f:
+            f.write(np.array([self.k, ts.value - 1], dtype="<u8").tobytes())
+            f.write(rec.tobytes())
+        return ts.value, n
 
     def kernel_ms(self, stage: str) -> float:
         ms = C.c_float()

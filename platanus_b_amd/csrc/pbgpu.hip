@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -71,6 +72,8 @@ struct pb_ctx {
     u64 ctable_cap = 0;
     unsigned ctable_k = 0;
     DevBuf chain_work, chain_rec, chain_seq;     // K7 chain compaction
+    DevBuf layout_work, layout_slots, layout_out, scan_sums, slot_blk;   // CT8 exact PREFIX_kmer_occ.bin layout
+    u64 layout_records = 0;
     u64 n_chains = 0, chain_seq_words = 0;
     void *chain_ptrs[2] = {nullptr, nullptr};
 
@@ -961,6 +964,7 @@ void pb_destroy(pb_ctx *ctx)
     release(ctx->index_table); release(ctx->nmask_cur); release(ctx->alive); release(ctx->d_read_start);
     release(ctx->contig_packed); release(ctx->contig_mask); release(ctx->ctable);
     release(ctx->chain_work); release(ctx->chain_rec); release(ctx->chain_seq);
+    release(ctx->layout_work); release(ctx->layout_slots); release(ctx->layout_out); release(ctx->scan_sums); release(ctx->slot_blk);
     for (auto &s : ctx->scratch) release(s);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);

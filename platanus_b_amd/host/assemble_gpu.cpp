@@ -158,12 +158,43 @@ struct Driver {
         avg_cov = avg_cov * avg_len / (avg_len - k[0] + 1.0);
     }
 
-    // PREFIX_kmer_occ.bin (counter.h:954-963, doubleHash.h:266-278).  The file holds a valid DoubleHash layout of the
-    // retained (key,count) set for the table size the reference would choose at this -m; the slot of each key follows
-    // insertion in ascending key order, NOT the reference's -t 1 first-occurrence order (CT8: byte-exact layout is
-    // produced by the oracle only).
+    // PREFIX_kmer_occ.bin (counter.h:954-963, doubleHash.h:266-278).  k <= 32: the device reproduces the reference's
+    // -t 1 slot layout (pb_kmer_occ_layout), the file is byte-identical.  k > 32: the reference dumps raw C++ objects
+    // (vptr + heap pointer per record) and is not reproducible even by itself; the file written here has the
+    // same header, table size, record format (pointers zeroed) and (key,count) set, keys inserted in ascending order.
     template <int W> void write_kmer_occ(u64 min_occ)
     {
+        if (W == 1) {
+            const u64 memory = opt.memory_gb * 1000000000ull;
+            long base = 16;                                                       // sizeof(pair<u64,u16>), counter.h:300
+            u64 dh = memory / base;
+            base = std::log(dh) / std::log(2);
+            dh = std::pow(2, base);
+            while (dh > memory) dh >>= 1;
+            u64 tsize = 0, nrec = 0;
+            {
+                Tick t("kmer_occ layout (device)");
+                chk(pb_kmer_occ_layout(ctx, dh, (unsigned)min_occ, &tsize, &nrec));
+            }
+            std::vector<u64> slots(nrec), keys(nrec);
+            std::vector<u16> counts(nrec);
+            chk(pb_kmer_occ_fetch(ctx, slots.data(), keys.data(), counts.data()));
+            Tick t("kmer_occ write");
+            FILE *f = fopen((opt.out_prefix + "_kmer_occ.bin").c_str(), "wb");
+            if (!f) throw std::runtime_error("cannot open " + opt.out_prefix + "_kmer_occ.bin");
+            const u64 kk = k[0], nm = tsize - 1;
+            fwrite(&kk, 8, 1, f);
+            fwrite(&nm, 8, 1, f);
+            std::vector<unsigned char> buf(nrec * 18);
+            for (u64 i = 0; i < nrec; ++i) {
+                memcpy(&buf[i * 18], &slots[i], 8);
+                memcpy(&buf[i * 18 + 8], &keys[i], 8);
+                memcpy(&buf[i * 18 + 16], &counts[i], 2);
+            }
+            if (nrec) fwrite(buf.data(), 18, nrec, f);
+            fclose(f);
+            return;
+        }
         u64 n = 0;
         chk(pb_retain(ctx, (unsigned)min_occ, &n));
         std::vector<u64> keys(n * W);
@@ -276,7 +307,11 @@ struct Driver {
         }
         g.delete_erroneous_iterative(length_cutoff, left_min, opt.verbose);
         avg_cov = avg_cov * (avg_len - kk + 1.0) / avg_len;
-        if (atoi(opt.bubble.c_str()) > 0) g.crush_bubble_iterative(avg_cov, opt.verbose);
+        if (atoi(opt.bubble.c_str()) > 0) {                     // assemble.cpp:520-526 (Q1: only -u >= 1 gets here)
+            if (opt.verbose) std::cerr << "AVE_KMER_COV_REMOVING_BUBBLE=" << avg_cov << std::endl;
+            g.crush_bubble_iterative(avg_cov, opt.verbose);
+            print_bubbles(opt.out_prefix + "_contigBubble.fa", g.bubbles, avg_len / (avg_len - kk + 1.0));
+        }
         // saveGraph(k, allReadFP): diff == 0, so no edge k-mer is stored and no read survives
         chk(pb_reads_restore(ctx));
         save_graph<W>(kk, kk);

@@ -80,6 +80,27 @@ inline void print_contigs(const std::string &path, const std::vector<ContigRecor
     fclose(f);
 }
 
+// graph.h:1586-1612 printBubble
+inline void print_bubbles(const std::string &path, const std::vector<ContigRecord> &recs, double ratio)
+{
+    FILE *f = fopen(path.c_str(), "w");
+    if (!f) throw std::runtime_error("cannot open " + path);
+    u64 num = 0;
+    for (const ContigRecord &r : recs) {
+        const u16 occ = r.cov * ratio + 0.5;
+        ++num;
+        fprintf(f, ">seq%llu_len%llu_cov%u\n", (unsigned long long)num, (unsigned long long)r.length, (unsigned)occ);
+        u64 j = 0;
+        for (; j < r.length; ++j) {
+            const u64 p = r.length - 1 - j;
+            fputc(bin2char((unsigned)((r.seq[p / 32] >> ((p % 32) * 2)) & 3)), f);
+            if ((j + 1) % 80 == 0) fputc('\n', f);
+        }
+        if (j % 80 != 0) fputc('\n', f);
+    }
+    fclose(f);
+}
+
 template <int W>
 struct Graph {
     typedef Key<W> K;
@@ -88,6 +109,7 @@ struct Graph {
     std::unordered_map<K, Junction, KeyHash<W>> junctions;       // junctionTable
     std::unordered_map<K, Straight, KeyHash<W>> left;            // leftStraightTable (key = head k-mer)
     std::unordered_map<K, Straight *, KeyHash<W>> right;         // rightStraightTable (key = tail k-mer)
+    std::vector<ContigRecord> bubbles;                           // bubbleFP of the last crush_bubble_iterative (graph.h:661-668)
 
     void set_k(unsigned kk) { k = kk; }
     void set_thresholds(double bubble, double branch) { bubble_th = bubble; branch_th = branch; }
@@ -567,6 +589,14 @@ struct Graph {
                     mx[b1]->coverage = std::min(tmp, static_cast<u64>(65534));
                     root->out ^= 1u << b2;
                     jn[b2]->out ^= 1u << (st[b2]->get(k - 1) + 4);
+                    {
+                        ContigRecord r;                                   // graph.h:661-668
+                        r.length = st[b2]->length + k - 1;
+                        r.cov = st[b2]->coverage;
+                        r.seq.assign((r.length + 31) / 32, 0);
+                        for (size_t i = 0; i < r.seq.size() && i < st[b2]->seq.size(); ++i) r.seq[i] = st[b2]->seq[i];
+                        bubbles.push_back(r);
+                    }
                     delete_straight(*st[b2]);
                     ++num;
                 }
@@ -577,6 +607,7 @@ struct Graph {
     void crush_bubble_iterative(double avg_cov, bool verbose)       // graph.h:1851-1870
     {
         if (verbose) std::cerr << "removing bubbles...\nBUBBLE_IDENTITY_THRESHOLD=" << bubble_th << std::endl;
+        bubbles.clear();
         u64 total = 0, n;
         do {
             n = crush_bubble(avg_cov);

@@ -28,7 +28,8 @@ CASES = {
     "c1": dict(genome=50_000, cov=50, seed=1, err=0.005, n_rate=0.0,
                runs={"multik": ["-k", "32", "-t", "1", "-m", "1"],
                      "occ": ["-k", "32", "-t", "1", "-m", "1", "-kmer_occ_only"],
-                     "s0": ["-k", "32", "-s", "0", "-t", "1", "-m", "1"]}),
+                     "s0": ["-k", "32", "-s", "0", "-t", "1", "-m", "1"],
+                     "u1": ["-k", "32", "-t", "1", "-m", "1", "-u", "1"]}),
     "c2": dict(genome=200_000, cov=40, seed=7, err=0.01, n_rate=0.001,
                runs={"multik_n2": ["-k", "32", "-t", "1", "-m", "1", "-n", "2"]}),
     "k45": dict(genome=20_000, cov=40, seed=11, err=0.005, n_rate=0.0,

@@ -48,7 +48,7 @@ def _run_case(manifest, name, run, tmp_path):
     return info, p.stderr
 
 
-@pytest.mark.parametrize("name,run", [("g5k", "multik"), ("g5k", "k21_s0"), ("c1", "s0"), ("c1", "multik"), ("k45", "multik_k45"), ("c2", "multik_n2")])
+@pytest.mark.parametrize("name,run", [("g5k", "multik"), ("g5k", "k21_s0"), ("c1", "s0"), ("c1", "multik"), ("k45", "multik_k45"), ("c2", "multik_n2"), ("c1", "u1")])
 def test_cli_contigs_and_histogram_identical_to_reference(name, run, manifest, tmp_path):
     assert os.path.exists(BIN), "platanus_b_amd/bin/platanus_b missing: run __graft_entry__.build()"
     info, _ = _run_case(manifest, name, run, tmp_path)
@@ -61,15 +61,17 @@ def test_cli_contigs_and_histogram_identical_to_reference(name, run, manifest, t
             assert filecmp.cmp(got, gold, shallow=False), fn
 
 
-def test_cli_kmer_occ_only(manifest, tmp_path):
-    """-kmer_occ_only: TSV byte-identical; PREFIX_kmer_occ.bin holds the same k, table size and (key,count) set as the
-    reference's file (slot layout: see DESIGN.md CT8 -- byte-exact layout is an oracle-only result so far)."""
+def test_cli_kmer_occ_only_byte_identical(manifest, tmp_path):
+    """-kmer_occ_only (BASELINE configs[1]'s mode): TSV and PREFIX_kmer_occ.bin byte-identical to the reference's files
+    (k = 32, -t 1 layout; md5 for the 1 MB file of the 50 kbp case)."""
     info, _ = _run_case(manifest, "g5k", "occ_n2", tmp_path)
     assert filecmp.cmp(tmp_path / "out_32merFrq.tsv", os.path.join(GOLDEN, "g5k.occ_n2.out_32merFrq.tsv"), shallow=False)
-    got = _decode_occ(tmp_path / "out_kmer_occ.bin", 1)
-    ref = _decode_occ(os.path.join(GOLDEN, "g5k.occ_n2.out_kmer_occ.bin"), 1)
-    assert got == ref
-    assert os.path.getsize(tmp_path / "out_kmer_occ.bin") == info["files"]["out_kmer_occ.bin"]["bytes"]
+    assert filecmp.cmp(tmp_path / "out_kmer_occ.bin", os.path.join(GOLDEN, "g5k.occ_n2.out_kmer_occ.bin"), shallow=False)
+    sub = tmp_path / "c1"
+    sub.mkdir()
+    info, _ = _run_case(manifest, "c1", "occ", sub)
+    for fn, meta in info["files"].items():
+        assert _md5(sub / fn) == meta["md5"], fn
 
 
 def test_cli_usage_and_errors(tmp_path):
@@ -77,3 +79,37 @@ def test_cli_usage_and_errors(tmp_path):
     assert p.returncode == 1 and "Usage platanus_b assemble" in p.stderr          # main.cpp:114-117
     p = subprocess.run([BIN, "assemble", "-bogus", "1"], capture_output=True, text=True)
     assert p.returncode == 1
+
+
+def _write_fasta(path, codes, width=60, lower_every=7):
+    with open(path, "w") as f:
+        for i, r in enumerate(codes):
+            s = "".join("ACGTN"[c] for c in r)
+            if i % lower_every == 0:
+                s = s.lower()
+            f.write(f">read{i}\n")
+            for j in range(0, len(s), width):
+                f.write(s[j:j + width] + "\n")
+
+
+def test_cli_fasta_multiline_lowercase_and_gzip_match_oracle_cli(tmp_path):
+    """Reader rules of assemble.cpp:790-986: multi-line FASTA records are joined, lower case is accepted (Char2Bin,
+    common.h:256), gzip input goes through `gzip -cd`.  Compared with the oracle's CLI on the same files."""
+    from platanus_b_amd import synth
+    oracle_cli = os.path.join(ROOT, "oracle", "pb_oracle")
+    assert os.path.exists(oracle_cli)
+    r1, r2 = synth.make_reads(8000, 30, seed=21, n_rate=0.002)
+    _write_fasta(tmp_path / "a.fa", r1)
+    _write_fasta(tmp_path / "b.fa", r2)
+    for tag, exe in (("gpu", BIN), ("cpu", oracle_cli)):
+        p = subprocess.run([exe, "assemble", "-k", "25", "-o", tag, "-f", "a.fa", "b.fa"], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+    assert filecmp.cmp(tmp_path / "gpu_contig.fa", tmp_path / "cpu_contig.fa", shallow=False)
+    assert filecmp.cmp(tmp_path / "gpu_25merFrq.tsv", tmp_path / "cpu_25merFrq.tsv", shallow=False)
+    # the same reads as gzip-compressed FASTQ
+    synth.write_fastq(str(tmp_path / "c_1.fq"), r1, 1)
+    synth.write_fastq(str(tmp_path / "c_2.fq"), r2, 2)
+    subprocess.run(["gzip", "-k", "c_1.fq", "c_2.fq"], cwd=tmp_path, check=True)
+    p = subprocess.run([BIN, "assemble", "-k", "25", "-o", "gz", "-f", "c_1.fq.gz", "c_2.fq.gz"], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert filecmp.cmp(tmp_path / "gz_contig.fa", tmp_path / "cpu_contig.fa", shallow=False)

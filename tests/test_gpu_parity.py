@@ -277,3 +277,34 @@ def test_exchange_and_merge_over_rccl_single_rank(gpu, oracle_built):
             assert np.array_equal(gk, ok) and np.array_equal(gc, ocn)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mem_bytes,cutoff", [(1 << 20, 1), (1 << 20, 2), (3 << 20, 1), (10 ** 9, 2)])
+def test_kmer_occ_bin_byte_exact_layout(mem_bytes, cutoff, gpu, oracle_built, tmp_path):
+    """CT8: PREFIX_kmer_occ.bin byte-identical to the -t 1 reference layout.  Small -m values make the 1024 stripe tables
+    tiny (64 / 128 slots), so the 32-probe limit, the spill passes and the iterateTimes increments are all exercised."""
+    from platanus_b_amd import synth
+    r1, r2 = synth.make_reads(40_000, 40, seed=12, n_rate=0.001)
+    codes = np.concatenate([r1, r2])
+    n, L = codes.shape
+    off = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
+    oc = oracle_built.OracleCounter()
+    dh = oc.count(codes.reshape(-1), off, 32, mem_bytes)
+    oc.write_table_binary(cutoff, str(tmp_path / "oracle.bin"))
+    g = gpu(0)
+    g.reads_append_matrix(codes)
+    g.make_kmer_read_distribution(32)
+    g.output_occurrence_table_binary(str(tmp_path / "gpu.bin"), cutoff, dh)
+    a, b = open(tmp_path / "gpu.bin", "rb").read(), open(tmp_path / "oracle.bin", "rb").read()
+    assert len(a) == len(b)
+    assert a == b
+
+
+def test_kmer_occ_bin_matches_reference_golden_file(gpu, manifest, tmp_path):
+    """The file the real reference wrote (`-k 32 -t 1 -m 1 -n 2 -kmer_occ_only`, tests/golden)."""
+    codes, off = case_reads(manifest["g5k"])
+    g = gpu(0)
+    g.reads_append_matrix(codes)
+    g.make_kmer_read_distribution(32)
+    g.output_occurrence_table_binary(str(tmp_path / "gpu.bin"), 2, 1 << 25)       # -m 1 -> 2^25 slots (counter.h:300-309)
+    assert open(tmp_path / "gpu.bin", "rb").read() == open(os.path.join(GOLDEN, "g5k.occ_n2.out_kmer_occ.bin"), "rb").read()

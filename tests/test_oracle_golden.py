@@ -27,12 +27,13 @@ def _args_to_kw(args):
         elif a == "-m": kw["memory_gb"] = int(next(it))
         elif a == "-t": next(it)
         elif a == "-kmer_occ_only": kw["kmer_occ_only"] = True
+        elif a == "-u": kw["bubble"] = next(it)
         else: raise AssertionError(a)
     return kw
 
 
 CASE_RUNS = [("g5k", "multik"), ("g5k", "occ_n2"), ("g5k", "k21_s0"), ("c1", "multik"), ("c1", "occ"), ("c1", "s0"),
-             ("c2", "multik_n2"), ("k45", "multik_k45")]
+             ("c2", "multik_n2"), ("k45", "multik_k45"), ("c1", "u1")]
 
 
 @pytest.mark.parametrize("name,run", CASE_RUNS)
