@@ -42,9 +42,19 @@ def make_genome(genome_len: int, seed: int) -> np.ndarray:
     return (rand_u64(seed, 0, genome_len) >> np.uint64(62)).astype(np.uint8)
 
 
+def make_haplotype2(genome: np.ndarray, seed: int, het: float) -> np.ndarray:
+    """Second haplotype: the genome with substitutions at rate `het` (bubbles in the de Bruijn graph)."""
+    n = genome.size
+    hit = rand_unit(seed, 40, n) < het
+    sub = (rand_u64(seed, 41, n) % np.uint64(3)).astype(np.uint8)
+    h2 = genome.copy()
+    h2[hit] = (h2[hit] + 1 + sub[hit]) & 3
+    return h2
+
+
 def make_reads(genome_len: int, coverage: float, seed: int, read_len: int = 150, err: float = 0.005,
                n_rate: float = 0.0, frag_mean: float = 350.0, frag_sd: float = 30.0,
-               genome: np.ndarray | None = None, pair_lo: int = 0, pair_hi: int | None = None):
+               genome: np.ndarray | None = None, pair_lo: int = 0, pair_hi: int | None = None, het: float = 0.0):
     """Return (r1, r2): uint8 [n_pairs, read_len] code matrices (0..3, 4 = N).
 
     n_pairs = floor(G*cov / (2*read_len)).  pair_lo/pair_hi select a sub-range of pairs (used to shard the
@@ -67,8 +77,13 @@ def make_reads(genome_len: int, coverage: float, seed: int, read_len: int = 150,
     start = (rand_unit(seed, 1, n, pair_lo) * (genome_len - flen + 1)).astype(np.int64)
     strand = (rand_u64(seed, 2, n, pair_lo) >> np.uint64(63)).astype(bool)
     ar = np.arange(read_len, dtype=np.int64)
-    left = genome[start[:, None] + ar[None, :]]                                   # 5' end of fragment, forward
-    right = 3 - genome[(start + flen - 1)[:, None] - ar[None, :]]                 # revcomp of 3' end
+    src = genome
+    hap = np.zeros(n, dtype=np.int64)
+    if het > 0:                                   # odd pairs are sampled from the second haplotype
+        src = np.concatenate([genome, make_haplotype2(genome, seed, het)])
+        hap = ((np.arange(pair_lo, pair_lo + n, dtype=np.int64) & 1) * genome_len)
+    left = src[(start + hap)[:, None] + ar[None, :]]                              # 5' end of fragment, forward
+    right = 3 - src[(start + hap + flen - 1)[:, None] - ar[None, :]]              # revcomp of 3' end
     r1 = np.where(strand[:, None], right, left).astype(np.uint8)
     r2 = np.where(strand[:, None], left, right).astype(np.uint8)
     for which, r in ((0, r1), (1, r2)):
@@ -136,6 +151,7 @@ if __name__ == "__main__":
     ap.add_argument("--err", type=float, default=0.005)
     ap.add_argument("--n-rate", type=float, default=0.0)
     ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--het", type=float, default=0.0)
     a = ap.parse_args()
-    n, L = write_pair_files(a.prefix, a.genome, a.cov, a.seed, err=a.err, n_rate=a.n_rate, read_len=a.read_len)
+    n, L = write_pair_files(a.prefix, a.genome, a.cov, a.seed, err=a.err, n_rate=a.n_rate, read_len=a.read_len, het=a.het)
     print(f"{n} pairs x 2 x {L} bp -> {a.prefix}_1.fq {a.prefix}_2.fq")

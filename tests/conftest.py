@@ -25,7 +25,7 @@ def manifest():
 def case_reads(case):
     """Reads of a golden case in the reference's -t 1 temp-file order: all of file 1, then all of file 2."""
     from platanus_b_amd import synth
-    r1, r2 = synth.make_reads(case["genome"], case["cov"], case["seed"], err=case["err"], n_rate=case["n_rate"])
+    r1, r2 = synth.make_reads(case["genome"], case["cov"], case["seed"], err=case["err"], n_rate=case["n_rate"], het=case.get("het", 0.0))
     codes = np.concatenate([r1, r2])
     n, L = codes.shape
     return codes, np.arange(n + 1, dtype=np.uint64) * np.uint64(L)

@@ -41,14 +41,14 @@ def _run_case(manifest, name, run, tmp_path):
     from platanus_b_amd import synth
     case = manifest[name]
     info = case["runs"][run]
-    synth.write_pair_files(str(tmp_path / "in"), case["genome"], case["cov"], case["seed"], err=case["err"], n_rate=case["n_rate"])
+    synth.write_pair_files(str(tmp_path / "in"), case["genome"], case["cov"], case["seed"], err=case["err"], n_rate=case["n_rate"], het=case.get("het", 0.0))
     p = subprocess.run([BIN, "assemble", *info["args"], "-o", "out", "-f", "in_1.fq", "in_2.fq"], cwd=tmp_path, capture_output=True, text=True,
                        timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
     return info, p.stderr
 
 
-@pytest.mark.parametrize("name,run", [("g5k", "multik"), ("g5k", "k21_s0"), ("c1", "s0"), ("c1", "multik"), ("k45", "multik_k45"), ("c2", "multik_n2"), ("c1", "u1")])
+@pytest.mark.parametrize("name,run", [("g5k", "multik"), ("g5k", "k21_s0"), ("c1", "s0"), ("c1", "multik"), ("k45", "multik_k45"), ("c2", "multik_n2"), ("c1", "u1"), ("het", "u1"), ("het", "u0")])
 def test_cli_contigs_and_histogram_identical_to_reference(name, run, manifest, tmp_path):
     assert os.path.exists(BIN), "platanus_b_amd/bin/platanus_b missing: run __graft_entry__.build()"
     info, _ = _run_case(manifest, name, run, tmp_path)
@@ -113,3 +113,16 @@ def test_cli_fasta_multiline_lowercase_and_gzip_match_oracle_cli(tmp_path):
     p = subprocess.run([BIN, "assemble", "-k", "25", "-o", "gz", "-f", "c_1.fq.gz", "c_2.fq.gz"], cwd=tmp_path, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     assert filecmp.cmp(tmp_path / "gz_contig.fa", tmp_path / "cpu_contig.fa", shallow=False)
+
+
+def test_cli_config3_full_multik_5mbp_md5(manifest, tmp_path):
+    """BASELINE configs[2]: 5 Mbp x 100x PE150, full multi-k assemble (k = 32 ... 109, 1- to 4-word keys).  The real
+    reference needed 1098 s (-t 8) for this input; its PREFIX_contig.fa / PREFIX_32merFrq.tsv are pinned by md5."""
+    import time
+    info, err = None, None
+    t0 = time.time()
+    info, err = _run_case(manifest, "cfg3", "multik", tmp_path)
+    for fn, meta in info["files"].items():
+        assert os.path.getsize(tmp_path / fn) == meta["bytes"], fn
+        assert _md5(tmp_path / fn) == meta["md5"], fn
+    print(f"config 3 incl. FASTQ generation: {time.time() - t0:.1f} s")

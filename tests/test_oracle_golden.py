@@ -33,7 +33,7 @@ def _args_to_kw(args):
 
 
 CASE_RUNS = [("g5k", "multik"), ("g5k", "occ_n2"), ("g5k", "k21_s0"), ("c1", "multik"), ("c1", "occ"), ("c1", "s0"),
-             ("c2", "multik_n2"), ("k45", "multik_k45"), ("c1", "u1")]
+             ("c2", "multik_n2"), ("k45", "multik_k45"), ("c1", "u1"), ("het", "u1"), ("het", "u0")]
 
 
 @pytest.mark.parametrize("name,run", CASE_RUNS)
