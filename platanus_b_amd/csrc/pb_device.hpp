@@ -115,6 +115,14 @@ __device__ __forceinline__ u64 mix64(u64 x)
     x ^= x >> 33;
     return x;
 }
+// inverse of mix64 (every step of the murmur3 finaliser is a bijection on 64 bits)
+__device__ __forceinline__ u64 unmix64(u64 x)
+{
+    x ^= x >> 33; x *= 0x9cb4b2f8129337dbull;
+    x ^= x >> 33; x *= 0x4f74430c22a54005ull;
+    x ^= x >> 33;
+    return x;
+}
 template <int W>
 __device__ __forceinline__ u64 key_hash(const DKey<W> &a)
 {

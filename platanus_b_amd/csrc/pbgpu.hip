@@ -420,6 +420,8 @@ merge_kernel(const u64 *__restrict__ keys, const u32 *__restrict__ counts, u64 n
 // K2+K3, partitioned form (k <= 32).  The v1 kernel above does two random device-scope atomics per window on
 // a multi-GB table and is bound by the atomic units (measured 18 ms for cfg2).  Here the random access is
 // moved into LDS:
+//   The partition buffers hold m = mix64(canonical key), a bijection, so the bucket index is simply the top l1+l2 bits
+//   of m, the key is recovered with unmix64, and a bucket's LDS slot needs only the remaining bits.
 //   part1_kernel  extract canonical k-mers from the packed stream and scatter them by hash digit 1 into
 //                 2^l1 level-1 buckets.  A block stages a tile of keys in LDS sorted by digit (LDS counting
 //                 sort), reserves one range per digit with a single global atomic, and copies every run with
@@ -433,7 +435,7 @@ merge_kernel(const u64 *__restrict__ keys, const u32 *__restrict__ counts, u64 n
 // everything of a flagged bucket is counted through the v1 global table instead (fallback, always correct).
 // ------------------------------------------------------------------------------------------------------
 #define PB_TILE 8192                 /* keys staged per block iteration: 64 KB of LDS                    */
-#define PB_PART_THREADS 1024         /* one 1024-lane block per CU (tile staging takes ~95 KB of its LDS): 16 waves */
+#define PB_PART_THREADS 512          /* two 512-lane blocks per CU (79 KB of LDS each): their phases overlap          */
 #define PB_TILE_ITEMS (PB_TILE / PB_PART_THREADS)
 #define PB_MAX_DIGITS 1024
 #define PB_BUCKET_CAP 2048           /* keys per final bucket                                             */
@@ -451,57 +453,53 @@ struct PartParams {
     u64 *scalars;                    // [0] instances [1] fallback overflow
 };
 
-__device__ __forceinline__ u64 part_hash(u64 key) { return mix64(key); }
+__device__ __forceinline__ u64 part_hash(u64 mixed_key) { return mixed_key; }     // buffers hold mix64(key): digits are its top bits
 
 // Scatter `nvalid` keys held in registers (kreg[j], valid bit j of vmask) into 2^bits destinations.
 // digit(key) = (part_hash(key) >> shift) & (2^bits - 1).  dst_of(d) gives base pointer, capacity and cursor.
 template <typename DST>
 __device__ __forceinline__ void tile_scatter(const u64 (&kreg)[PB_TILE_ITEMS], u32 vmask, unsigned shift, unsigned bits, DST dst,
-                                             u64 *skeys, u16 *sdig, u32 *shist, u32 *soff, u32 *sbase)
+                                             u64 *skeys, u32 *shist, u32 *soff, u32 *sbase)
 {
     const unsigned nd = 1u << bits;
-    if (threadIdx.x < nd) shist[threadIdx.x] = 0;
+    for (unsigned i = threadIdx.x; i < nd; i += PB_PART_THREADS) shist[i] = 0;
     __syncthreads();
-    u16 dreg[PB_TILE_ITEMS];
 #pragma unroll
-    for (int j = 0; j < PB_TILE_ITEMS; ++j) {
-        dreg[j] = (u16)((unsigned)(part_hash(kreg[j]) >> shift) & (nd - 1));
-        if (vmask & (1u << j)) atomicAdd(&shist[dreg[j]], 1u);
-    }
+    for (int j = 0; j < PB_TILE_ITEMS; ++j)
+        if (vmask & (1u << j)) atomicAdd(&shist[(unsigned)(kreg[j] >> shift) & (nd - 1)], 1u);
     __syncthreads();
-    // exclusive scan of shist[0..nd) -> soff (nd <= 1024 = one bin per lane: wave scan + 16 wave totals)
+    // exclusive scan of shist[0..nd) -> soff (nd <= 1024: two bins per lane, wave scan + wave totals)
     {
         __shared__ u32 wtot[PB_PART_THREADS / 64];
         const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        const u32 v = threadIdx.x < nd ? shist[threadIdx.x] : 0;
-        u32 x = v;
+        const unsigned i0 = threadIdx.x * 2;
+        const u32 a = i0 < nd ? shist[i0] : 0, b = i0 + 1 < nd ? shist[i0 + 1] : 0;
+        u32 x = a + b;
         for (int o = 1; o < 64; o <<= 1) { const u32 y = __shfl_up(x, o, 64); if ((int)lane >= o) x += y; }
         if (lane == 63) wtot[wave] = x;
         __syncthreads();
-        u32 run = x - v;
+        u32 run = x - (a + b);
         for (unsigned w = 0; w < wave; ++w) run += wtot[w];
-        if (threadIdx.x < nd) { soff[threadIdx.x] = run; sbase[threadIdx.x] = run; }
+        if (i0 < nd) { soff[i0] = run; sbase[i0] = run; }
+        if (i0 + 1 < nd) { soff[i0 + 1] = run + a; sbase[i0 + 1] = run + a; }
     }
     __syncthreads();
     // place keys (sbase doubles as the running LDS cursor)
 #pragma unroll
     for (int j = 0; j < PB_TILE_ITEMS; ++j)
-        if (vmask & (1u << j)) {
-            const u32 pos = atomicAdd(&sbase[dreg[j]], 1u);
-            skeys[pos] = kreg[j];
-            sdig[pos] = dreg[j];
-        }
+        if (vmask & (1u << j)) skeys[atomicAdd(&sbase[(unsigned)(kreg[j] >> shift) & (nd - 1)], 1u)] = kreg[j];
     __syncthreads();
     // reserve one global range per non-empty digit
-    if (threadIdx.x < nd) {
-        const u32 cnt = shist[threadIdx.x];
-        sbase[threadIdx.x] = cnt ? dst.reserve(threadIdx.x, cnt) : 0;
+    for (unsigned d = threadIdx.x; d < nd; d += PB_PART_THREADS) {
+        const u32 cnt = shist[d];
+        sbase[d] = cnt ? dst.reserve(d, cnt) : 0;
     }
     __syncthreads();
     const u32 total = soff[nd - 1] + shist[nd - 1];
     for (u32 i = threadIdx.x; i < total; i += PB_PART_THREADS) {
-        const unsigned d = sdig[i];
-        dst.store(d, sbase[d] + (i - soff[d]), skeys[i]);
+        const u64 key = skeys[i];
+        const unsigned d = (unsigned)(key >> shift) & (nd - 1);
+        dst.store(d, sbase[d] + (i - soff[d]), key);
     }
     __syncthreads();
 }
@@ -522,8 +520,8 @@ struct Dst1 {
     {
         if (pos < p.cap1) p.bucket1[((u64)d * PB_XCD + x) * p.cap1 + pos] = key;
         else {   // level-1 overflow: the key is counted in the fallback table and its final bucket is flagged
-            p.flag2[(unsigned)(part_hash(key) >> (64 - p.l1 - p.l2))] = 1;
-            DKey<1> k1; k1.w[0] = key;
+            p.flag2[(unsigned)(key >> (64 - p.l1 - p.l2))] = 1;
+            DKey<1> k1; k1.w[0] = unmix64(key);
             if (!table_add<1>(p.fallback, k1, 1u, 1024u)) p.scalars[1] = 1;
         }
     }
@@ -538,7 +536,7 @@ struct Dst2 {
         if (pos < PB_BUCKET_CAP) p.bucket2[(u64)b * PB_BUCKET_CAP + pos] = key;
         else {
             p.flag2[b] = 1;
-            DKey<1> k1; k1.w[0] = key;
+            DKey<1> k1; k1.w[0] = unmix64(key);
             if (!table_add<1>(p.fallback, k1, 1u, 1024u)) p.scalars[1] = 1;
         }
     }
@@ -564,11 +562,10 @@ __device__ __forceinline__ u64 lds_kmer(const u64 *__restrict__ sp, u32 rel, uns
 #define PB_TILE_PWORDS (PB_TILE / 32 + 2)      /* packed words covering a tile + one k-mer of overhang */
 #define PB_TILE_MWORDS (PB_TILE / 64 + 2)
 
-__global__ void __launch_bounds__(PB_PART_THREADS)
+__global__ void __launch_bounds__(PB_PART_THREADS, 4)
 part1_kernel(const u64 *__restrict__ packed, const u64 *__restrict__ nmask, u64 stream_len, u64 n_words64, unsigned k, PartParams p)
 {
     __shared__ u64 skeys[PB_TILE];
-    __shared__ u16 sdig[PB_TILE];
     __shared__ u32 shist[PB_MAX_DIGITS], soff[PB_MAX_DIGITS], sbase[PB_MAX_DIGITS];
     __shared__ u64 spack[PB_TILE_PWORDS], smask[PB_TILE_MWORDS];
     const u64 n_tiles = (stream_len + PB_TILE - 1) / PB_TILE;
@@ -588,23 +585,22 @@ part1_kernel(const u64 *__restrict__ packed, const u64 *__restrict__ nmask, u64 
             kreg[j] = 0;
             if (g0 + rel + k <= stream_len && !lds_window_has_n(smask, rel, k)) {
                 DKey<1> f; f.w[0] = lds_kmer(spack, rel, k);
-                kreg[j] = key_canon<1>(f, k).w[0];
+                kreg[j] = mix64(key_canon<1>(f, k).w[0]);
                 vmask |= 1u << j;
             }
         }
         local += __popc(vmask);
-        tile_scatter(kreg, vmask, 64 - p.l1, p.l1, Dst1{p, xcd}, skeys, sdig, shist, soff, sbase);
+        tile_scatter(kreg, vmask, 64 - p.l1, p.l1, Dst1{p, xcd}, skeys, shist, soff, sbase);
     }
     for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o, 64);
     if ((threadIdx.x & 63) == 0 && local) atomicAdd(&p.scalars[0], local);
 }
 
 // grid = (tiles per level-1 sub-stream, 2^l1 * PB_XCD)
-__global__ void __launch_bounds__(PB_PART_THREADS)
+__global__ void __launch_bounds__(PB_PART_THREADS, 4)
 part2_kernel(PartParams p)
 {
     __shared__ u64 skeys[PB_TILE];
-    __shared__ u16 sdig[PB_TILE];
     __shared__ u32 shist[PB_MAX_DIGITS], soff[PB_MAX_DIGITS], sbase[PB_MAX_DIGITS];
     const unsigned sub = blockIdx.y;             // level-1 sub-stream = bucket * PB_XCD + xcd
     const unsigned b1 = sub / PB_XCD;
@@ -620,7 +616,7 @@ part2_kernel(PartParams p)
             kreg[j] = 0;
             if (i < n) { kreg[j] = src[i]; vmask |= 1u << j; }
         }
-        tile_scatter(kreg, vmask, 64 - p.l1 - p.l2, p.l2, Dst2{p, b1}, skeys, sdig, shist, soff, sbase);
+        tile_scatter(kreg, vmask, 64 - p.l1 - p.l2, p.l2, Dst2{p, b1}, skeys, shist, soff, sbase);
     }
 }
 
@@ -672,86 +668,93 @@ scan_add_kernel(u64 *__restrict__ out, const u64 *__restrict__ block_sums)
 // One block per final bucket: LDS-resident open-addressing occurrence hashing.  The bucket's records are written at
 // bucket_base[b] (exclusive prefix of the bucket sizes, an upper bound of the records before it), so no global
 // atomic is on the block's critical path; n_occ[b] records are valid, a later pass closes the gaps.
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 4)
 bucket_count_kernel(PartParams p, u64 *__restrict__ out_keys, u32 *__restrict__ out_counts, const u64 *__restrict__ bucket_base,
                     u32 *__restrict__ n_occ_out)
 {
-    __shared__ u64 lkeys[PB_BUCKET_SLOTS];
-    __shared__ u32 lcnt[PB_BUCKET_SLOTS];
+    // one u64 per slot: (m << logp) | count.  The top logp bits of m are the bucket index, so they are implied; the count
+    // of a k-mer inside a bucket is at most PB_BUCKET_CAP = 2048 < 2^12 <= 2^logp.  Insert = one LDS CAS (new key) or one
+    // LDS 64-bit add (seen key); 32 KB of LDS per bucket -> 5 resident blocks per CU.
+    __shared__ u64 lslot[PB_BUCKET_SLOTS];
     __shared__ u32 wtot[4];
-    const unsigned n_buckets = 1u << (p.l1 + p.l2);
+    const unsigned logp = p.l1 + p.l2;
+    const unsigned n_buckets = 1u << logp;
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int KPL = PB_BUCKET_CAP / 256;         // keys per lane
     constexpr int SPL = PB_BUCKET_SLOTS / 256;       // table slots per lane (contiguous: lane t owns slots [t*SPL, (t+1)*SPL))
 
-    // software pipeline: the keys of the block's next bucket are loaded while the current one is emitted
+    // software pipeline: the keys of the block's next bucket are loaded while the current one is emitted.  All KPL loads
+    // are issued unconditionally (bucket regions have a fixed size), so they do not wait for the bucket's size to arrive.
     u64 kin[KPL];
-    u32 n = 0;
-    bool flagged = false;
+    u32 n = 0, flagged = 0;
     auto fetch = [&](unsigned b) {
-        n = 0; flagged = false;
-        if (b >= n_buckets) return;
-        n = p.cursor2[b];
-        if (n > PB_BUCKET_CAP) n = PB_BUCKET_CAP;
-        flagged = p.flag2[b] != 0;
-        const u64 *src = p.bucket2 + (u64)b * PB_BUCKET_CAP;
+        const unsigned bb = b < n_buckets ? b : n_buckets - 1;
+        const u64 *src = p.bucket2 + (u64)bb * PB_BUCKET_CAP;
 #pragma unroll
-        for (int j = 0; j < KPL; ++j) {
-            const u32 i = (u32)j * 256 + threadIdx.x;
-            kin[j] = i < n ? src[i] : PB_EMPTY_KEY;
-        }
+        for (int j = 0; j < KPL; ++j) kin[j] = src[(u32)j * 256 + threadIdx.x];
+        n = b < n_buckets ? p.cursor2[bb] : 0;
+        flagged = p.flag2[bb];
     };
     fetch(blockIdx.x);
     for (unsigned b = blockIdx.x; b < n_buckets; b += gridDim.x) {
-        const u32 cur_n = n;
-        const bool cur_flagged = flagged;
+        u32 cur_n = n;
+        if (cur_n > PB_BUCKET_CAP) cur_n = PB_BUCKET_CAP;
+        const bool cur_flagged = flagged != 0;
         if (cur_n == 0) { fetch(b + gridDim.x); continue; }          // n_occ_out[b] stays 0 (memset)
         if (cur_flagged) {           // flagged: count through the global fallback table
 #pragma unroll
             for (int j = 0; j < KPL; ++j)
-                if (kin[j] != PB_EMPTY_KEY) {
-                    DKey<1> k1; k1.w[0] = kin[j];
+                if ((u32)j * 256 + threadIdx.x < cur_n) {
+                    DKey<1> k1; k1.w[0] = unmix64(kin[j]);
                     if (!table_add<1>(p.fallback, k1, 1u, 1024u)) p.scalars[1] = 1;
                 }
             fetch(b + gridDim.x);
             continue;
         }
-        for (unsigned i = threadIdx.x; i < PB_BUCKET_SLOTS; i += 256) { lkeys[i] = PB_EMPTY_KEY; lcnt[i] = 0; }
+        for (unsigned i = threadIdx.x; i < PB_BUCKET_SLOTS; i += 256) lslot[i] = ~0ull;
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < KPL; ++j) {
-            const u64 key = kin[j];
-            if (key == PB_EMPTY_KEY) continue;
-            u32 s = (u32)part_hash(key) & (PB_BUCKET_SLOTS - 1);     // low hash bits: independent of the bucket digits
+            if ((u32)j * 256 + threadIdx.x >= cur_n) continue;
+            const u64 want = kin[j] << logp;                         // key bits without the implied bucket index, count = 0
+            u32 s = (u32)(kin[j] >> 3) & (PB_BUCKET_SLOTS - 1);      // low bits of m: independent of the bucket digits
             while (true) {
-                u64 prev = lkeys[s];
-                if (prev == PB_EMPTY_KEY) prev = atomicCAS(&lkeys[s], PB_EMPTY_KEY, key);
-                if (prev == PB_EMPTY_KEY || prev == key) { atomicAdd(&lcnt[s], 1u); break; }
+                u64 v = lslot[s];
+                if (v == ~0ull) {
+                    v = atomicCAS(&lslot[s], ~0ull, want | 1ull);
+                    if (v == ~0ull) break;
+                }
+                if ((v >> logp) == (want >> logp)) { atomicAdd(&lslot[s], 1ull); break; }
                 s = (s + 1) & (PB_BUCKET_SLOTS - 1);
             }
         }
         fetch(b + gridDim.x);                         // next bucket's loads fly during the emit below
         __syncthreads();
-        // emit: every lane counts its occupied slots, one block-wide exclusive scan gives its output offset
-        u32 cnts[SPL];
+        // emit: every lane counts its occupied slots; a block-wide exclusive scan gives its offset in a dense LDS list
+        // (the table is ~10 % full: the dense list makes the unmix + store work proportional to the records, not the slots)
         u32 mine = 0;
+        u64 sl[SPL];
 #pragma unroll
-        for (int j = 0; j < SPL; ++j) { cnts[j] = lcnt[threadIdx.x * SPL + j]; mine += cnts[j] != 0; }
+        for (int j = 0; j < SPL; ++j) { sl[j] = lslot[threadIdx.x * SPL + j]; mine += sl[j] != ~0ull; }
         u32 x = mine;
         for (int o = 1; o < 64; o <<= 1) { const u32 y = __shfl_up(x, o, 64); if ((int)lane >= o) x += y; }
         if (lane == 63) wtot[wave] = x;
-        __syncthreads();
+        __syncthreads();                              // also: every lane has read its slots, the table may be overwritten
         u32 off = x - mine;
         for (unsigned w = 0; w < wave; ++w) off += wtot[w];
-        u64 pos = bucket_base[b] + off;
+        const u32 total = wtot[0] + wtot[1] + wtot[2] + wtot[3];
 #pragma unroll
         for (int j = 0; j < SPL; ++j)
-            if (cnts[j]) {
-                out_keys[pos] = lkeys[threadIdx.x * SPL + j];
-                out_counts[pos] = cnts[j];
-                ++pos;
-            }
-        if (threadIdx.x == 255) n_occ_out[b] = off + mine;
+            if (sl[j] != ~0ull) lslot[off++] = sl[j];          // dense list reuses the table's storage (off <= own first slot)
+        __syncthreads();
+        const u64 gbase = bucket_base[b];
+        const u64 top = (u64)b << (64 - logp);
+        for (u32 i = threadIdx.x; i < total; i += 256) {
+            const u64 v = lslot[i];
+            out_keys[gbase + i] = unmix64((v >> logp) | top);
+            out_counts[gbase + i] = (u32)(v & ((1ull << logp) - 1));
+        }
+        if (threadIdx.x == 0) n_occ_out[b] = total;
         __syncthreads();
     }
 }
@@ -1157,7 +1160,7 @@ static int count_partitioned(pb_ctx *ctx, unsigned k, bool *done)
     int rc;
     *done = false;
     const u64 windows = ctx->stream_len;          // upper bound on counted windows
-    unsigned logp = 10;
+    unsigned logp = 12;               // >= 12: a bucket's LDS slot keeps the count in the low logp bits (count <= 2048)
     while (((u64)1536 << logp) < windows && logp < 20) ++logp;
     if (((u64)1536 << logp) < windows) return PB_OK;          // too large for 2^20 buckets: caller uses v1
     PartParams p;
@@ -1201,7 +1204,7 @@ static int count_partitioned(pb_ctx *ctx, unsigned k, bool *done)
         {
             StageTimer t1(ctx, "part1");
             const u64 n_tiles = (ctx->stream_len + PB_TILE - 1) / PB_TILE;
-            part1_kernel<<<grid_for(n_tiles, 1, 256 * 4), PB_PART_THREADS, 0, ctx->stream>>>((const u64 *)ctx->packed.p, cur_mask(ctx),
+            part1_kernel<<<grid_for(n_tiles, 1, 256 * 8), PB_PART_THREADS, 0, ctx->stream>>>((const u64 *)ctx->packed.p, cur_mask(ctx),
                                                                                 ctx->stream_len, (ctx->stream_len + 63) / 64 + PB_STREAM_PAD_WORDS64, k, p);
             HIPCHK(hipGetLastError());
             if ((rc = t1.stop()) != PB_OK) return rc;
