@@ -64,9 +64,23 @@ def cpu_baseline(sample_cov=20.0, threads=None):
                     break
             p.kill()
             p.wait()
+            # the device build of the same CLI on the same sample files: end-to-end wall time of the full multi-k assemble
+            # (FASTQ parse + upload + every k round + FASTA write); reported next to the baseline, not part of `value`
+            gpu_cli = os.path.join(ROOT, "platanus_b_amd", "bin", "platanus_b")
+            extra = None
+            if os.path.exists(gpu_cli):
+                g0 = time.perf_counter()
+                r = subprocess.run([gpu_cli, "assemble", "-k", str(K), "-o", os.path.join(tmp, "g"), "-f", os.path.join(tmp, "s_1.fq"),
+                                    os.path.join(tmp, "s_2.fq")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                if r.returncode == 0:
+                    extra = {"wall_s": time.perf_counter() - g0, "what": "platanus_b_amd/bin/platanus_b assemble -k 32 (full multi-k, FASTQ in, "
+                             "contig.fa out) on the cpu_baseline sample files"}
             if t0 is not None and t1 is not None:
-                return {"value": instances / (t1 - t0), "unit": "k-mers/s", "cores": threads, "kind": "reference",
-                        "sample": sample + f", -t {threads} -m 16 (reference defaults), {t1 - t0:.1f} s"}
+                out = {"value": instances / (t1 - t0), "unit": "k-mers/s", "cores": threads, "kind": "reference",
+                       "sample": sample + f", -t {threads} -m 16 (reference defaults), {t1 - t0:.1f} s"}
+                if extra:
+                    out["gpu_assemble_same_sample"] = extra
+                return out
         finally:
             subprocess.run(["rm", "-rf", tmp])
     # CPU port (oracle restatement, single thread)
