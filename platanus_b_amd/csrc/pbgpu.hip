@@ -385,6 +385,10 @@ static int count_partitioned(pb_ctx *ctx, unsigned k, bool *done)
     const u64 windows = ctx->stream_len;          // upper bound on counted windows
     unsigned logp = 12;               // >= 12: a bucket's LDS slot keeps the count in the low logp bits (count <= 2048)
     while (((u64)1536 << logp) < windows && logp < 20) ++logp;
+    if (const char *fl = getenv("PB_FORCE_LOGP")) {            // tests: exercise other digit widths on small inputs
+        const int v = atoi(fl);
+        if (v >= 12 && v <= 20 && ((u64)1536 << v) >= windows) logp = (unsigned)v;
+    }
     if (((u64)1536 << logp) < windows) return PB_OK;          // too large for 2^20 buckets: caller uses v1
     PartParams p;
     p.l1 = (logp + 1) / 2;

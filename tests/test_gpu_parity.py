@@ -308,3 +308,44 @@ def test_kmer_occ_bin_matches_reference_golden_file(gpu, manifest, tmp_path):
     g.make_kmer_read_distribution(32)
     g.output_occurrence_table_binary(str(tmp_path / "gpu.bin"), 2, 1 << 25)       # -m 1 -> 2^25 slots (counter.h:300-309)
     assert open(tmp_path / "gpu.bin", "rb").read() == open(os.path.join(GOLDEN, "g5k.occ_n2.out_kmer_occ.bin"), "rb").read()
+
+
+@pytest.mark.parametrize("logp", [13, 17, 20])
+def test_partitioned_path_other_bucket_counts(logp, gpu, oracle_built, monkeypatch):
+    """2^13 .. 2^20 final buckets (digit widths 6..10 bits, i.e. up to 1024 LDS counting-sort bins per level): the sizes
+    a 100 Mbp x 100x shard would use, forced on a small input."""
+    from platanus_b_amd import synth
+    monkeypatch.setenv("PB_COUNT_PATH", "partitioned")
+    monkeypatch.setenv("PB_FORCE_LOGP", str(logp))
+    r1, r2 = synth.make_reads(50_000, 50, seed=60 + logp, n_rate=0.001)
+    codes = np.concatenate([r1, r2])
+    n, L = codes.shape
+    off = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
+    oc = _oracle(codes, off, 32, oracle_built)
+    ohist, omax = oc.occ_hist()
+    g = gpu(0)
+    g.reads_append_matrix(codes)
+    hist = g.make_kmer_read_distribution(32)
+    assert g.kernel_ms("part1") > 0
+    assert np.array_equal(hist, ohist) and g.max_occ == omax
+    ok, ocn = oc.retain(1)
+    g.retain(1)
+    gk, gc = g.fetch_retained()
+    assert np.array_equal(gk, ok) and np.array_equal(gc, ocn)
+
+
+def test_low_coverage_mostly_distinct_kmers(gpu, oracle_built, monkeypatch):
+    """2x coverage: almost every k-mer instance is distinct (the opposite regime of the benchmark); both counting paths."""
+    from platanus_b_amd import synth
+    r1, r2 = synth.make_reads(300_000, 2, seed=91, err=0.02)
+    codes = np.concatenate([r1, r2])
+    n, L = codes.shape
+    off = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
+    oc = _oracle(codes, off, 31, oracle_built)
+    ohist, omax = oc.occ_hist()
+    for path in ("partitioned", "direct"):
+        monkeypatch.setenv("PB_COUNT_PATH", path)
+        g = gpu(0)
+        g.reads_append_matrix(codes)
+        hist = g.make_kmer_read_distribution(31)
+        assert np.array_equal(hist, ohist) and g.max_occ == omax, path
