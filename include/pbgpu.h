@@ -146,6 +146,13 @@ int pb_count_considering_contigs(pb_ctx *ctx, unsigned k, uint64_t *occ_hist, ui
 int pb_kmer_occ_layout(pb_ctx *ctx, uint64_t dh_size, unsigned min_occ, uint64_t *table_size, uint64_t *n_records);
 int pb_kmer_occ_fetch(pb_ctx *ctx, uint64_t *slots, uint64_t *keys, uint16_t *counts);
 
+/* ---- SURVEY 8(f) "next" row 1: `kmer_divide`'s look-ups (ContigDivider::getOccurrenceArray, kmer_divide.cpp:150-197) ----- */
+/* pb_occ_table_load: the (key,count) records of a PREFIX_kmer_occ.bin (read on the host) become the resident lookup table.
+ * pb_occ_lookup: sequences given as codes 0..3 / 4 = N with offsets[n_seqs+1]; out[offsets[i] - offsets[0] + j] = occurrence of the
+ * canonical k-mer starting at position j of sequence i, 0 if absent, if the window covers an N or if j > len_i - k. */
+int pb_occ_table_load(pb_ctx *ctx, unsigned k, const uint64_t *keys, const uint16_t *counts, uint64_t n);
+int pb_occ_lookup(pb_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, uint64_t n_seqs, uint16_t *out);
+
 /* ---- timing of the last call, measured with HIP events on the library's stream ------------------------- */
 /* stage names: "pack", "count", "hist", "compact", "sort", "adjacency", ... ; returns PB_EINVAL if unknown */
 int pb_last_kernel_ms(const pb_ctx *ctx, const char *stage, float *ms);

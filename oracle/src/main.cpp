@@ -2,13 +2,76 @@
 // output files as `platanus_b assemble` (assemble.cpp:55-110), uncompressed input only.
 #include "assemble.hpp"
 #include "fastx.hpp"
+#include "../../platanus_b_amd/host/kmer_divide.hpp"
+#include <unordered_map>
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
 
+// kmer_divide with CPU look-ups (ContigDivider::getOccurrenceArray, kmer_divide.cpp:150-197, restated per position)
+template <int W>
+static void cpu_occurrence(unsigned k, const std::vector<pbo::u64> &keys, const std::vector<pbo::u16> &counts, const pbh::ContigSet &cs,
+                           std::vector<std::vector<pbo::u64>> &occ)
+{
+    using namespace pbo;
+    std::unordered_map<Key<W>, u16, KeyHash<W>> table;
+    for (size_t i = 0; i < counts.size(); ++i) { Key<W> key; for (int w = 0; w < W; ++w) key.w[w] = keys[i * W + w]; table[key] = counts[i]; }
+    occ.resize(cs.size());
+    for (size_t i = 0; i < cs.size(); ++i) {
+        const std::string &s = cs.seq[i];
+        occ[i].assign(s.size() - k + 1, 0);
+        for (u64 j = 0; j + k <= s.size(); ++j) {
+            bool has_n = false;
+            Kmer<W> km(k);
+            for (unsigned b = 0; b < k; ++b) { const unsigned c = (unsigned char)s[j + b]; if (c > 3) { has_n = true; break; } km.push_right(c); }
+            if (has_n) continue;
+            auto it = table.find(km.canon());
+            if (it != table.end()) occ[i][j] = it->second;
+        }
+    }
+}
+
+static int oracle_kmer_divide(int argc, char **argv)
+{
+    pbh::DivideOptions o;
+    for (int i = 2; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto val = [&]() -> std::string { return i + 1 < argc ? argv[++i] : ""; };
+        if (a == "-o") o.out_prefix = val();
+        else if (a == "-k") o.occ_file = val();
+        else if (a == "-r") o.rate = atof(val().c_str());
+        else if (a == "-R") o.mask_rate = atof(val().c_str());
+        else if (a == "-t" || a == "-tmp") val();
+        else if (a == "-recalc_cov") o.recalc_cov = true;
+        else if (a == "-mask") o.mask = true;
+        else if (a == "-f") { while (i + 1 < argc && argv[i + 1][0] != '-') o.files.push_back(argv[++i]); }
+        else return 1;
+    }
+    unsigned k = 0;
+    std::vector<pbo::u64> keys;
+    std::vector<pbo::u16> counts;
+    pbh::read_kmer_occ(o.occ_file, k, keys, counts);
+    pbh::ContigSet cs;
+    pbo::u64 read_length = 100, max_k = 100;
+    for (size_t i = 0; i < o.files.size(); ++i) pbh::read_contig_fasta(o.files[i], cs, i == 0, read_length, max_k);
+    std::vector<std::vector<pbo::u64>> occ;
+    switch (pbh::words_for_k(k)) {
+    case 1: cpu_occurrence<1>(k, keys, counts, cs, occ); break;
+    case 2: cpu_occurrence<2>(k, keys, counts, cs, occ); break;
+    case 3: cpu_occurrence<3>(k, keys, counts, cs, occ); break;
+    case 4: cpu_occurrence<4>(k, keys, counts, cs, occ); break;
+    default: cpu_occurrence<5>(k, keys, counts, cs, occ); break;
+    }
+    pbh::divide_and_write(o, k, cs, occ, read_length, max_k, true);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     using namespace pbo;
+    if (argc >= 2 && strcmp(argv[1], "kmer_divide") == 0) {
+        try { return oracle_kmer_divide(argc, argv); } catch (const std::exception &e) { std::cerr << "Error: " << e.what() << std::endl; return 2; }
+    }
     if (argc < 2 || strcmp(argv[1], "assemble") != 0) {
         std::cerr << "usage: pb_oracle assemble [platanus_b assemble options]" << std::endl;
         return 1;

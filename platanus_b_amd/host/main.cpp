@@ -1,6 +1,7 @@
 // platanus_b (MI355X build): same command line as the reference's `platanus_b assemble` (main.cpp:70-149,
 // baseCommand.cpp:56-136, assemble.cpp:55-110).  Only the `assemble` command exists here.
 #include "assemble_gpu.hpp"
+#include "kmer_divide.hpp"
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
@@ -28,10 +29,41 @@ static void usage()
               << "\n\nOutputs:\n    PREFIX_contig.fa\n    PREFIX_kmerFrq.tsv\n\nNote, PREFIX is specified by -o\n" << std::endl;
 }
 
+namespace pbh { int run_kmer_divide_gpu(const DivideOptions &opt, int device, bool verbose); }
+
+static int main_kmer_divide(int argc, char **argv)       // options: kmer_divide.cpp:28-38
+{
+    pbh::DivideOptions o;
+    int device = 0;
+    for (int i = 2; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto val = [&]() -> std::string { if (i + 1 >= argc) { std::cerr << "missing value for " << a << std::endl; exit(1); } return argv[++i]; };
+        if (a == "-o") o.out_prefix = val();
+        else if (a == "-k") o.occ_file = val();
+        else if (a == "-r") o.rate = atof(val().c_str());
+        else if (a == "-R") o.mask_rate = atof(val().c_str());
+        else if (a == "-t" || a == "-tmp") val();
+        else if (a == "-gpu") device = atoi(val().c_str());
+        else if (a == "-recalc_cov") o.recalc_cov = true;
+        else if (a == "-mask") o.mask = true;
+        else if (a == "-f") { while (i + 1 < argc && argv[i + 1][0] != '-') o.files.push_back(argv[++i]); }
+        else { std::cerr << "\nUsage: platanus_b kmer_divide [Options] (-o -f -k -r -R -recalc_cov -mask -t -tmp)" << std::endl; return 1; }
+    }
+    if (o.files.empty()) { std::cerr << "Error: not specified contig file!!" << std::endl; return 1; }
+    if (o.occ_file.empty()) { std::cerr << "Error: not specified kmer occurrence file!!!" << std::endl; return 1; }
+    try {
+        return pbh::run_kmer_divide_gpu(o, device, true);
+    } catch (const std::exception &e) {
+        std::cerr << "Error: " << e.what() << std::endl;
+        return 2;
+    }
+}
+
 int main(int argc, char **argv)
 {
+    if (argc >= 2 && strcmp(argv[1], "kmer_divide") == 0) return main_kmer_divide(argc, argv);
     if (argc < 2 || strcmp(argv[1], "assemble") != 0) {
-        std::cerr << "Usage: platanus_b Command [options]\n\nCommand: assemble" << std::endl;
+        std::cerr << "Usage: platanus_b Command [options]\n\nCommand: assemble, kmer_divide" << std::endl;
         return 1;
     }
     pbh::GpuAssembleOptions o;

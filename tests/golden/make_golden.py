@@ -36,7 +36,10 @@ CASES = {
                 runs={"multik_k45": ["-k", "45", "-t", "1", "-m", "1"]}),
     # two haplotypes differing at 0.4 % of the positions: bubbles, crushed with -u 1 (only -u >= 1 reaches crushBubble, Q1)
     "het": dict(genome=30_000, cov=60, seed=13, err=0.003, n_rate=0.0, het=0.004,
-                runs={"u1": ["-k", "32", "-t", "1", "-m", "1", "-u", "1"], "u0": ["-k", "32", "-t", "1", "-m", "1"]}),
+                runs={"u1": ["-k", "32", "-t", "1", "-m", "1", "-u", "1"], "u0": ["-k", "32", "-t", "1", "-m", "1"],
+                      "occ_n1": ["-k", "32", "-t", "1", "-m", "1", "-n", "1", "-kmer_occ_only"]},
+                # `kmer_divide` on the u0 contigs with the occ_n1 table
+                kmer_divide={"kd_default": [], "kd_mask": ["-mask"], "kd_r05": ["-r", "0.5"]}),
 }
 KEEP_WHOLE_BELOW = 400_000      # bytes; larger outputs are pinned by md5 only
 
@@ -79,6 +82,19 @@ def main():
                     if os.path.getsize(p) <= KEEP_WHOLE_BELOW:
                         shutil.copy(p, os.path.join(HERE, f"{name}.{run}.{fn}"))
                 manifest[name]["runs"][run] = {"args": args, "files": files}
+                print(name, run, {k: v["bytes"] for k, v in files.items()})
+            for run, args in c.get("kmer_divide", {}).items():
+                d = os.path.join(tmp, run)
+                os.makedirs(d)
+                subprocess.run([REF, "kmer_divide", "-k", "../occ_n1/out_kmer_occ.bin", "-f", "../u0/out_contig.fa", "-o", "out", *args], cwd=d,
+                               check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                files = {}
+                for fn in sorted(os.listdir(d)):
+                    p = os.path.join(d, fn)
+                    files[fn] = {"md5": md5(p), "bytes": os.path.getsize(p)}
+                    if os.path.getsize(p) <= KEEP_WHOLE_BELOW:
+                        shutil.copy(p, os.path.join(HERE, f"{name}.{run}.{fn}"))
+                manifest[name].setdefault("kmer_divide", {})[run] = {"args": args, "files": files}
                 print(name, run, {k: v["bytes"] for k, v in files.items()})
         finally:
             shutil.rmtree(tmp)
