@@ -3,6 +3,8 @@
 #include "assemble.hpp"
 #include "fastx.hpp"
 #include "../../platanus_b_amd/host/kmer_divide.hpp"
+#include "../../platanus_b_amd/host/merge.hpp"
+#include "graph.hpp"
 #include <unordered_map>
 #include <cstdlib>
 #include <cstring>
@@ -29,6 +31,78 @@ static void cpu_occurrence(unsigned k, const std::vector<pbo::u64> &keys, const 
             if (it != table.end()) occ[i][j] = it->second;
         }
     }
+}
+
+// merge.cpp:86-147 with the oracle's own table (DoubleHash) and k-mer-level DFS
+template <int W>
+static void oracle_merge_run(const pbh::MergeOptions &opt, const pbh::MergeContigs &mc, unsigned k, double avg_cov, pbo::u64 read_length)
+{
+    using namespace pbo;
+    Counter<W> c;
+    c.k = k;
+    u64 total = 0;
+    for (const std::string &s : mc.seq) total += s.size() - k + 1;
+    const u64 upper = std::max(table_size_for_keys(total), table_size_for_memory(opt.memory_gb * 1000000000ull, W));
+    c.table.resize(upper);
+    for (size_t i = 0; i < mc.seq.size(); ++i) {                                    // counter.h:545-578
+        const u64 v = std::max<u64>(mc.coverage[i], opt.min_cov);
+        for_each_kmer<W>((const uint8_t *)mc.seq[i].data(), (unsigned)mc.seq[i].size(), k, [&](const Key<W> &key) {
+            const u64 s = c.table.find_any(key);
+            c.table.keys[s] = key;
+            if (c.table.vals[s] < v) c.table.vals[s] = (u16)v;
+        });
+    }
+    c.occ_hist.assign(65535, 0);
+    for (u64 s = 0; s < c.table.size(); ++s)                                        // writeKmerDistribution (counter.h:783-805)
+        if (c.table.vals[s] != 0) { c.kmer_keys.push_back(c.table.keys[s]); c.kmer_vals.push_back(c.table.vals[s]); ++c.occ_hist[c.table.vals[s]]; c.table.vals[s] = 0; }
+    c.find_max_occ();
+    std::vector<Key<W>> sorted = c.sorted_keys(0);
+    c.load_kmers(0, upper);
+    Graph<W> g;
+    g.set_k(k);
+    g.set_thresholds(atof(opt.bubble.c_str()), opt.branch);
+    g.make_initial(c.table, sorted);
+    c.table.release();
+    g.cut_branch_iterative(true);
+    g.crush_bubble_iterative(avg_cov, true);
+    std::vector<ContigRecord> contigs, junctions;
+    g.save_contig_simple(contigs, 1.0);
+    g.save_junction(junctions, 1.0);
+    print_contigs(opt.out_prefix + "_merged.fa", contigs, 1.0, (double)read_length, (long)k, "seq", false);
+    print_contigs(opt.out_prefix + "_mergedJunctionKmer.fa", junctions, 1.0, (double)read_length, (long)k, "junction", false);
+}
+
+static int oracle_merge(int argc, char **argv)
+{
+    pbh::MergeOptions o;
+    for (int i = 2; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto val = [&]() -> std::string { return i + 1 < argc ? argv[++i] : ""; };
+        if (a == "-o") o.out_prefix = val();
+        else if (a == "-c") o.min_cov = atoi(val().c_str());
+        else if (a == "-k") o.k_factor = atof(val().c_str());
+        else if (a == "-l") o.len_factor = atof(val().c_str());
+        else if (a == "-u") o.bubble = val();
+        else if (a == "-d") o.branch = atof(val().c_str());
+        else if (a == "-m") o.memory_gb = atoi(val().c_str());
+        else if (a == "-tmp") val();
+        else if (a == "-f") { while (i + 1 < argc && argv[i + 1][0] != '-') o.files.push_back(argv[++i]); }
+        else return 1;
+    }
+    const pbo::u64 read_length = pbh::first_header_read_length(o.files.at(0));
+    const unsigned k = (unsigned)(o.k_factor * read_length + 0.5);
+    const pbo::u64 min_len = (pbo::u64)(o.len_factor * read_length + 0.5);
+    pbh::MergeContigs mc;
+    for (const std::string &f : o.files) pbh::read_contigs_cut_n(f, min_len, mc);
+    const double avg_cov = pbh::merge_average_coverage(mc);
+    switch (pbh::words_for_k(k)) {
+    case 1: oracle_merge_run<1>(o, mc, k, avg_cov, read_length); break;
+    case 2: oracle_merge_run<2>(o, mc, k, avg_cov, read_length); break;
+    case 3: oracle_merge_run<3>(o, mc, k, avg_cov, read_length); break;
+    case 4: oracle_merge_run<4>(o, mc, k, avg_cov, read_length); break;
+    default: oracle_merge_run<5>(o, mc, k, avg_cov, read_length); break;
+    }
+    return 0;
 }
 
 static int oracle_kmer_divide(int argc, char **argv)
@@ -69,6 +143,9 @@ static int oracle_kmer_divide(int argc, char **argv)
 int main(int argc, char **argv)
 {
     using namespace pbo;
+    if (argc >= 2 && strcmp(argv[1], "merge") == 0) {
+        try { return oracle_merge(argc, argv); } catch (const std::exception &e) { std::cerr << "Error: " << e.what() << std::endl; return 2; }
+    }
     if (argc >= 2 && strcmp(argv[1], "kmer_divide") == 0) {
         try { return oracle_kmer_divide(argc, argv); } catch (const std::exception &e) { std::cerr << "Error: " << e.what() << std::endl; return 2; }
     }

@@ -2,6 +2,7 @@
 // baseCommand.cpp:56-136, assemble.cpp:55-110).  Only the `assemble` command exists here.
 #include "assemble_gpu.hpp"
 #include "kmer_divide.hpp"
+#include "merge.hpp"
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
@@ -29,7 +30,34 @@ static void usage()
               << "\n\nOutputs:\n    PREFIX_contig.fa\n    PREFIX_kmerFrq.tsv\n\nNote, PREFIX is specified by -o\n" << std::endl;
 }
 
-namespace pbh { int run_kmer_divide_gpu(const DivideOptions &opt, int device, bool verbose); }
+namespace pbh { int run_kmer_divide_gpu(const DivideOptions &opt, int device, bool verbose); int run_merge_gpu(const MergeOptions &opt, int device, bool verbose); }
+
+static int main_merge(int argc, char **argv)             // options: merge.cpp:29-39
+{
+    pbh::MergeOptions o;
+    int device = 0;
+    for (int i = 2; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto val = [&]() -> std::string { if (i + 1 >= argc) { std::cerr << "missing value for " << a << std::endl; exit(1); } return argv[++i]; };
+        if (a == "-o") o.out_prefix = val();
+        else if (a == "-c") o.min_cov = atoi(val().c_str());
+        else if (a == "-k") o.k_factor = atof(val().c_str());
+        else if (a == "-l") o.len_factor = atof(val().c_str());
+        else if (a == "-u") o.bubble = val();
+        else if (a == "-d") o.branch = atof(val().c_str());
+        else if (a == "-m") o.memory_gb = atoi(val().c_str());
+        else if (a == "-tmp") val();
+        else if (a == "-gpu") device = atoi(val().c_str());
+        else if (a == "-f") { while (i + 1 < argc && argv[i + 1][0] != '-') o.files.push_back(argv[++i]); }
+        else { std::cerr << "\nUsage: platanus_b merge [Options] (-o -f -c -k -l -u -d -m -tmp)" << std::endl; return 1; }
+    }
+    try {
+        return pbh::run_merge_gpu(o, device, true);
+    } catch (const std::exception &e) {
+        std::cerr << "Error: " << e.what() << std::endl;
+        return 2;
+    }
+}
 
 static int main_kmer_divide(int argc, char **argv)       // options: kmer_divide.cpp:28-38
 {
@@ -62,8 +90,9 @@ static int main_kmer_divide(int argc, char **argv)       // options: kmer_divide
 int main(int argc, char **argv)
 {
     if (argc >= 2 && strcmp(argv[1], "kmer_divide") == 0) return main_kmer_divide(argc, argv);
+    if (argc >= 2 && strcmp(argv[1], "merge") == 0) return main_merge(argc, argv);
     if (argc < 2 || strcmp(argv[1], "assemble") != 0) {
-        std::cerr << "Usage: platanus_b Command [options]\n\nCommand: assemble, kmer_divide" << std::endl;
+        std::cerr << "Usage: platanus_b Command [options]\n\nCommand: assemble, kmer_divide, merge" << std::endl;
         return 1;
     }
     pbh::GpuAssembleOptions o;

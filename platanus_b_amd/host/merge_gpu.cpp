@@ -1,0 +1,88 @@
+// `platanus_b merge` on the device path (merge.cpp:86-147).
+#include "merge.hpp"
+#include "device_graph.hpp"
+#include <iostream>
+
+extern "C" {
+#include "../../include/pbgpu.h"
+}
+
+namespace pbh {
+
+template <int W>
+static void merge_run(pb_ctx *ctx, const MergeOptions &opt, const MergeContigs &mc, unsigned k, double avg_cov, u64 read_length, bool verbose)
+{
+    auto chk = [&](int rc) { if (rc != PB_OK) throw std::runtime_error(std::string("libpbgpu: ") + pb_last_error(ctx)); };
+    // makeKmerReadDistributionFromContig: every k-mer of every piece, value = max(coverage, -c)
+    if (verbose) std::cerr << "K = " << k << ", loading kmers from contigs...\n";
+    std::string bases;
+    std::vector<u64> off{0};
+    std::vector<u16> vals;
+    for (size_t i = 0; i < mc.seq.size(); ++i) {
+        bases += mc.seq[i];
+        off.push_back(bases.size());
+        vals.push_back((u16)std::max<u64>(mc.coverage[i], opt.min_cov));
+    }
+    u64 nw = 0, nd = 0, max_occ = 0, n = 0;
+    std::vector<u64> hist(PB_OCC_BINS);
+    chk(pb_contig_table_build(ctx, k, (const uint8_t *)bases.data(), off.data(), vals.data(), vals.size(), &nw));
+    chk(pb_count_considering_contigs(ctx, k, hist.data(), &max_occ, &nd));        // no reads resident: just the contig table
+    if (verbose) std::cerr << "loading kmers..." << std::endl;
+    chk(pb_retain(ctx, 0, &n));                                                    // sortedKeyFromKmerFile(0) + loadKmer(0, ...)
+    std::vector<u64> keys(n * W);
+    std::vector<u16> counts(n);
+    std::vector<uint8_t> adj(n), orient(n);
+    std::vector<uint32_t> nbr(2 * n), chain_of(n);
+    chk(pb_fetch_retained(ctx, keys.data(), counts.data()));
+    if (verbose) std::cerr << "connecting kmers..." << std::endl;
+    chk(pb_graph_adjacency(ctx, adj.data(), nbr.data()));
+    u64 nc = 0, words = 0;
+    chk(pb_graph_chains(ctx, &nc, &words));
+    std::vector<uint32_t> ch_len(nc), ch_a(nc), ch_b(nc);
+    std::vector<u64> ch_sum(nc), ch_woff(nc), ch_seq(words);
+    chk(pb_graph_fetch_chains(ctx, chain_of.data(), orient.data(), ch_len.data(), ch_sum.data(), ch_a.data(), ch_b.data(), ch_woff.data(), ch_seq.data()));
+    DeviceGraphInput<W> in;
+    in.k = k; in.n = n; in.keys = keys.data(); in.counts = counts.data(); in.adj = adj.data(); in.nbr = nbr.data();
+    ChainSet cs;
+    cs.n_chains = nc; cs.chain_of = chain_of.data(); cs.orient = orient.data(); cs.len = ch_len.data(); cs.sum = ch_sum.data();
+    cs.end_a = ch_a.data(); cs.end_b = ch_b.data(); cs.seq_woff = ch_woff.data(); cs.seq = ch_seq.data();
+    Graph<W> g;
+    g.set_k(k);
+    g.set_thresholds(atof(opt.bubble.c_str()), opt.branch);
+    make_initial_from_chains(g, in, cs);
+    g.cut_branch_iterative(verbose);
+    g.crush_bubble_iterative(avg_cov, verbose);
+    std::vector<ContigRecord> contigs, junctions;
+    g.save_contig_simple(contigs, 1.0);
+    g.save_junction(junctions, 1.0);
+    print_contigs(opt.out_prefix + "_merged.fa", contigs, 1.0, (double)read_length, (long)k, "seq", false);
+    print_contigs(opt.out_prefix + "_mergedJunctionKmer.fa", junctions, 1.0, (double)read_length, (long)k, "junction", false);
+}
+
+int run_merge_gpu(const MergeOptions &opt, int device, bool verbose)
+{
+    if (opt.files.empty()) throw std::runtime_error("not specified contig file");
+    const u64 read_length = first_header_read_length(opt.files[0]);
+    const unsigned k = (unsigned)(opt.k_factor * read_length + 0.5);
+    const u64 min_len = (u64)(opt.len_factor * read_length + 0.5);
+    if (k < 1 || k > PB_MAX_K) throw std::runtime_error("k out of range for the device path (1..160)");
+    MergeContigs mc;
+    for (const std::string &f : opt.files) read_contigs_cut_n(f, min_len, mc);
+    if (mc.seq.empty()) throw std::runtime_error("no contig passes the length filter");
+    const double avg_cov = merge_average_coverage(mc);
+    pb_ctx *ctx = nullptr;
+    if (pb_create(device, &ctx) != PB_OK) throw std::runtime_error(std::string("libpbgpu: ") + pb_last_error(nullptr));
+    try {
+        switch (words_for_k(k)) {
+        case 1: merge_run<1>(ctx, opt, mc, k, avg_cov, read_length, verbose); break;
+        case 2: merge_run<2>(ctx, opt, mc, k, avg_cov, read_length, verbose); break;
+        case 3: merge_run<3>(ctx, opt, mc, k, avg_cov, read_length, verbose); break;
+        case 4: merge_run<4>(ctx, opt, mc, k, avg_cov, read_length, verbose); break;
+        default: merge_run<5>(ctx, opt, mc, k, avg_cov, read_length, verbose); break;
+        }
+    } catch (...) { pb_destroy(ctx); throw; }
+    pb_destroy(ctx);
+    return 0;
+}
+
+} // namespace pbh

@@ -39,7 +39,9 @@ CASES = {
                 runs={"u1": ["-k", "32", "-t", "1", "-m", "1", "-u", "1"], "u0": ["-k", "32", "-t", "1", "-m", "1"],
                       "occ_n1": ["-k", "32", "-t", "1", "-m", "1", "-n", "1", "-kmer_occ_only"]},
                 # `kmer_divide` on the u0 contigs with the occ_n1 table
-                kmer_divide={"kd_default": [], "kd_mask": ["-mask"], "kd_r05": ["-r", "0.5"]}),
+                kmer_divide={"kd_default": [], "kd_mask": ["-mask"], "kd_r05": ["-r", "0.5"]},
+                # `merge` of the u0 contigs: k = 150 (5 words), 75 (3 words), 30 (1 word)
+                merge={"mg_k150": ["-m", "1"], "mg_k75": ["-m", "1", "-k", "0.5", "-l", "1.0"], "mg_k30_u1": ["-m", "1", "-k", "0.2", "-l", "0.5", "-u", "1"]}),
 }
 KEEP_WHOLE_BELOW = 400_000      # bytes; larger outputs are pinned by md5 only
 
@@ -95,6 +97,19 @@ def main():
                     if os.path.getsize(p) <= KEEP_WHOLE_BELOW:
                         shutil.copy(p, os.path.join(HERE, f"{name}.{run}.{fn}"))
                 manifest[name].setdefault("kmer_divide", {})[run] = {"args": args, "files": files}
+                print(name, run, {k: v["bytes"] for k, v in files.items()})
+            for run, args in c.get("merge", {}).items():
+                d = os.path.join(tmp, run)
+                os.makedirs(d)
+                subprocess.run([REF, "merge", "-f", "../u0/out_contig.fa", "-o", "out", *args], cwd=d, check=True, stdout=subprocess.DEVNULL,
+                               stderr=subprocess.DEVNULL)
+                files = {}
+                for fn in sorted(os.listdir(d)):
+                    p = os.path.join(d, fn)
+                    files[fn] = {"md5": md5(p), "bytes": os.path.getsize(p)}
+                    if os.path.getsize(p) <= KEEP_WHOLE_BELOW:
+                        shutil.copy(p, os.path.join(HERE, f"{name}.{run}.{fn}"))
+                manifest[name].setdefault("merge", {})[run] = {"args": args, "files": files}
                 print(name, run, {k: v["bytes"] for k, v in files.items()})
         finally:
             shutil.rmtree(tmp)
