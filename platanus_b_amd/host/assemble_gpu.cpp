@@ -18,6 +18,9 @@
 #include <fstream>
 #include <sstream>
 #include <tuple>
+#include <thread>
+#include <sys/mman.h>
+#include <sys/stat.h>
 
 extern "C" {
 #include "../../include/pbgpu.h"
@@ -337,8 +340,9 @@ template <typename F> void dispatch_w(unsigned k, F &&f)
     else throw std::runtime_error("k > 160 is not supported by the device path");
 }
 
-// FASTA/FASTQ reader with the reference's line rules (assemble.cpp:790-986); bases are handed over as ASCII,
-// the device applies Char2Bin (common.h:256)
+// FASTA/FASTQ reader with the reference's line rules (assemble.cpp:790-986); bases are handed over as ASCII, the device
+// applies Char2Bin (common.h:256).  The file is slurped once and split with memchr; sequence lines are appended straight
+// into `bases` (the reference's `read += oneLine` followed by the flush into the temp file).
 void read_file(const std::string &path, std::string &bases, std::vector<u64> &off)
 {
     FILE *fp = nullptr;
@@ -346,47 +350,67 @@ void read_file(const std::string &path, std::string &bases, std::vector<u64> &of
     const size_t L = path.size();
     if (L > 3 && path.compare(L - 3, 3, ".gz") == 0) { fp = popen(("gzip -cd " + path).c_str(), "r"); piped = true; }
     else if (L > 4 && path.compare(L - 4, 4, ".bz2") == 0) { fp = popen(("bzip2 -cd " + path).c_str(), "r"); piped = true; }
-    else fp = fopen(path.c_str(), "r");
+    else fp = fopen(path.c_str(), "rb");
     if (!fp) throw std::runtime_error("cannot open " + path);
-    std::string line, read;
-    char buf[1 << 16];
-    auto getline_fp = [&](std::string &out) -> bool {
-        out.clear();
-        while (fgets(buf, sizeof buf, fp)) {
-            const size_t n = strlen(buf);
-            if (n && buf[n - 1] == '\n') { out.append(buf, n - 1); return true; }
-            out.append(buf, n);
+    std::string buf;
+    const char *data = nullptr;
+    size_t size = 0;
+    void *map = MAP_FAILED;
+    if (!piped) {                                 // plain file: parse straight out of the page cache
+        struct stat st;
+        if (fstat(fileno(fp), &st) == 0 && st.st_size > 0) {
+            map = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fileno(fp), 0);
+            if (map != MAP_FAILED) { data = (const char *)map; size = (size_t)st.st_size; madvise(map, size, MADV_SEQUENTIAL); }
         }
-        return !out.empty();
+    }
+    if (map == MAP_FAILED) {
+        std::vector<char> chunk(16u << 20);
+        size_t got;
+        while ((got = fread(chunk.data(), 1, chunk.size(), fp)) > 0) buf.append(chunk.data(), got);
+        data = buf.data();
+        size = buf.size();
+    }
+    if (piped) pclose(fp); else fclose(fp);
+    struct Unmap { void *m; size_t n; ~Unmap() { if (m != MAP_FAILED) munmap(m, n); } } unmap{map, size};
+    const char *p = data, *end = p + size;
+    const char *ls = nullptr;
+    size_t len = 0;
+    auto next_line = [&]() -> bool {            // std::getline: a last line without '\n' counts, nothing after the final '\n'
+        if (p >= end) return false;
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+        ls = p;
+        len = (size_t)((nl ? nl : end) - p);
+        p = nl ? nl + 1 : end;
+        return true;
     };
+    if (!next_line()) throw std::runtime_error("empty read file " + path);
+    const bool fastq = len > 0 && ls[0] == '@';
+    if (!fastq && !(len > 0 && ls[0] == '>')) throw std::runtime_error("Read file exception!!\nRead file is not FASTA/FASTQ format.");
+    bases.reserve(bases.size() + size / 2);
+    u64 read_start = bases.size();             // the current read = bases[read_start, bases.size())
     auto flush = [&]() {
-        if (read.length() >= 500000) throw std::runtime_error("Read file exception!!\nread length is too long");   // common.h:465-467
-        bases += read;
+        if (bases.size() - read_start >= 500000) throw std::runtime_error("Read file exception!!\nread length is too long");   // common.h:465-467
         off.push_back(bases.size());
-        read.clear();
+        read_start = bases.size();
     };
-    if (!getline_fp(line)) { if (piped) pclose(fp); else fclose(fp); throw std::runtime_error("empty read file " + path); }
-    const bool fastq = line[0] == '@';
-    if (!fastq && line[0] != '>') throw std::runtime_error("Read file exception!!\nRead file is not FASTA/FASTQ format.");
     if (fastq) {
         bool flag = true;
-        while (getline_fp(line)) {
-            if (line.length() == 0) continue;
-            if (line[0] != '@') {
-                if (flag && line[0] != '+') read += line; else flag = false;
+        while (next_line()) {
+            if (len == 0) continue;
+            if (ls[0] != '@') {
+                if (flag && ls[0] != '+') bases.append(ls, len); else flag = false;
             } else {
-                if (read.length() != 0) flush();
+                if (bases.size() != read_start) flush();
                 flag = true;
             }
         }
     } else {
-        while (getline_fp(line)) {
-            if (line.empty() || line[0] != '>') read += line;
-            else if (read.length() != 0) flush();
+        while (next_line()) {
+            if (len == 0 || ls[0] != '>') bases.append(ls, len);
+            else if (bases.size() != read_start) flush();
         }
     }
     flush();                                               // trailing read, written even when empty
-    if (piped) pclose(fp); else fclose(fp);
 }
 
 } // namespace
@@ -404,20 +428,36 @@ int run_assemble_gpu(const GpuAssembleOptions &opt)
     std::get<4>(d.graphs).set_thresholds(bubble, opt.branch);
 
     const auto t_start = std::chrono::steady_clock::now();
-    for (const std::string &f : opt.files) {
-        Tick t("read files + upload/pack");
-        std::string bases;
-        std::vector<u64> off{0};
-        read_file(f, bases, off);
-        const u64 n = off.size() - 1;
-        // hand the file over in batches of ~64 MB of bases
-        u64 lo = 0;
-        while (lo < n) {
-            u64 hi = lo;
-            while (hi < n && off[hi + 1] - off[lo] < (64ull << 20)) ++hi;
-            if (hi == lo) ++hi;
-            d.chk(pb_reads_append(d.ctx, (const uint8_t *)bases.data(), off.data() + lo, hi - lo, 1));
-            lo = hi;
+    // the input files are parsed concurrently (one host thread per file, at most 8 at a time) and handed to the device in
+    // the order of the command line, which is the order of the reference's temp file 0 at -t 1
+    const size_t nf = opt.files.size();
+    std::vector<std::string> fbases(nf);
+    std::vector<std::vector<u64>> foff(nf, std::vector<u64>{0});
+    std::vector<std::string> ferr(nf);
+    for (size_t base = 0; base < nf; base += 8) {
+        const size_t hi_f = std::min(nf, base + 8);
+        {
+            Tick t("read + parse files (host threads)");
+            std::vector<std::thread> th;
+            for (size_t i = base; i < hi_f; ++i)
+                th.emplace_back([&, i]() { try { read_file(opt.files[i], fbases[i], foff[i]); } catch (const std::exception &e) { ferr[i] = e.what(); if (ferr[i].empty()) ferr[i] = "read error"; } });
+            for (auto &t2 : th) t2.join();
+        }
+        for (size_t i = base; i < hi_f; ++i) {
+            if (!ferr[i].empty()) throw std::runtime_error(ferr[i]);
+            Tick t("upload + pack reads (H2D + device)");
+            const std::vector<u64> &off = foff[i];
+            const u64 n = off.size() - 1;
+            u64 lo = 0;                          // batches of ~256 MB of bases
+            while (lo < n) {
+                u64 hi = lo;
+                while (hi < n && off[hi + 1] - off[lo] < (256ull << 20)) ++hi;
+                if (hi == lo) ++hi;
+                d.chk(pb_reads_append(d.ctx, (const uint8_t *)fbases[i].data(), off.data() + lo, hi - lo, 1));
+                lo = hi;
+            }
+            std::string().swap(fbases[i]);
+            std::vector<u64>().swap(foff[i]);
         }
     }
     d.k.assign(1, opt.k0);
