@@ -558,7 +558,7 @@ int pb_retain(pb_ctx *ctx, unsigned min_occ, uint64_t *n_keys)
     if ((rc = ensure(ctx, sk_a, n * 8)) != PB_OK) return rc;
     if ((rc = ensure(ctx, sk_b, n * 8)) != PB_OK) return rc;
     if ((rc = ensure(ctx, pv, n * 4 * 2)) != PB_OK) return rc;
-    if ((rc = ensure(ctx, cn, (u64)256 * n_tiles * 4)) != PB_OK) return rc;
+    if ((rc = ensure(ctx, cn, ((u64)256 * n_tiles + (u64)256 * n_tiles / RS_SCAN_CHUNK + 16) * 4)) != PB_OK) return rc;   // digit counts + scan block sums
     u32 *perm_a = (u32 *)pv.p, *perm_b = perm_a + n;
     StageTimer tm(ctx, "sort");
     iota_kernel<<<grid_for(n, 256), 256, 0, ctx->stream>>>(perm_a, n);
