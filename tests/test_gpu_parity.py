@@ -349,3 +349,62 @@ def test_low_coverage_mostly_distinct_kmers(gpu, oracle_built, monkeypatch):
         g.reads_append_matrix(codes)
         hist = g.make_kmer_read_distribution(31)
         assert np.array_equal(hist, ohist) and g.max_occ == omax, path
+
+
+def _superk_case(gpu, oracle_built, codes, k, cutoffs=(1, 3)):
+    n, L = codes.shape
+    off = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
+    oc = _oracle(codes, off, k, oracle_built)
+    ohist, omax = oc.occ_hist()
+    g = gpu(0)
+    g.reads_append_matrix(codes)
+    hist = g.make_kmer_read_distribution(k)
+    assert g.kernel_ms("part1") > 0
+    assert np.array_equal(hist, ohist) and g.max_occ == omax
+    assert g.n_distinct == int(ohist.sum())
+    for cutoff in cutoffs:
+        ok, ocn = oc.retain(cutoff)
+        assert g.retain(cutoff) == len(ok)
+        gk, gc = g.fetch_retained()
+        assert np.array_equal(gk, ok) and np.array_equal(gc, ocn)
+    return g
+
+
+@pytest.mark.parametrize("k", [32, 31, 25, 21, 20, 14, 13, 9, 2, 1])
+def test_superkmer_count_path_matches_oracle(k, gpu, oracle_built, monkeypatch):
+    """Super-k-mer records + minimizer buckets + LDS counting (kernels_superk.inc) forced on a small input with Ns:
+    every window width w = k - m + 1 class (w >= 8 uses the a8 window minimum, w < 8 the direct one, k < m has w = 1)."""
+    from platanus_b_amd import synth
+    monkeypatch.setenv("PB_COUNT_PATH", "superk")
+    r1, r2 = synth.make_reads(60_000, 40, seed=140 + k, n_rate=0.002)
+    _superk_case(gpu, oracle_built, np.concatenate([r1, r2]), k)
+
+
+@pytest.mark.parametrize("bits", [2, 9, 15, 18])
+def test_superkmer_other_bucket_counts(bits, gpu, oracle_built, monkeypatch):
+    """4 .. 2^18 minimizer buckets: 4 buckets overflow their LDS tables and go through the global table, 2^18 is what a
+    3 G-window shard would use (longest records shrink to 21 windows)."""
+    from platanus_b_amd import synth
+    monkeypatch.setenv("PB_COUNT_PATH", "superk")
+    monkeypatch.setenv("PB_FORCE_SKB", str(bits))
+    r1, r2 = synth.make_reads(50_000, 50, seed=160 + bits, n_rate=0.001)
+    _superk_case(gpu, oracle_built, np.concatenate([r1, r2]), 32, cutoffs=(1,))
+
+
+def test_superkmer_heavy_hitter_and_low_complexity(gpu, oracle_built, monkeypatch):
+    """Poly-A reads (one minimizer for the whole read, one 32-mer with 357000 instances) and dinucleotide repeats:
+    runs are cut every L positions, the bucket overflows its record capacity, results must not change."""
+    from platanus_b_amd import synth
+    monkeypatch.setenv("PB_COUNT_PATH", "superk")
+    r1, r2 = synth.make_reads(20_000, 30, seed=177)
+    poly = np.zeros((3000, 150), dtype=np.uint8)
+    di = np.tile(np.array([1, 2], dtype=np.uint8), (500, 75))
+    _superk_case(gpu, oracle_built, np.concatenate([r1, poly, di, r2]), 32, cutoffs=(2,))
+
+
+def test_superkmer_low_coverage_mostly_distinct(gpu, oracle_built, monkeypatch):
+    """2x coverage, 2 % errors: nearly every instance is a distinct key, far more than the LDS tables are sized for."""
+    from platanus_b_amd import synth
+    monkeypatch.setenv("PB_COUNT_PATH", "superk")
+    r1, r2 = synth.make_reads(300_000, 2, seed=191, err=0.02)
+    _superk_case(gpu, oracle_built, np.concatenate([r1, r2]), 31, cutoffs=(1,))
