@@ -176,13 +176,13 @@ def main():
         achieved = instances * BYTES_PER_INSTANCE / (k_ms * 1e-3) / 1e9
         parts = {st: float(np.mean(v)) for st, v in stage_ms.items()}
         partitioned = parts["part1"] > 0
-        kernel = ("part1_kernel + part2_kernel + bucket_count_kernel + bucket_compact_kernel (partitioned counting pass)"
+        kernel = ("sk_part1_kernel + sk_part2_kernel + sk_bucket_kernel + sk_flagged_kernel (super-k-mer counting pass)"
                   if partitioned else "count_kernel<1> (direct global-atomic counting pass)")
         # HBM bytes per counting pass from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes
         # of this same command, corrected as MI355X_MICROARCH.md prescribes): profiles/r01_hbm_traffic.json.  Only quoted
         # when the run is the profiled workload and path.
         traffic = None
-        tj = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+        tj = os.path.join(ROOT, "profiles", "r01_hbm_traffic_superk.json")
         if partitioned and a.genome == GENOME and world == 1 and os.path.exists(tj):
             traffic = json.load(open(tj)).get("hbm_bytes_per_counting_pass")
         out = {
@@ -197,7 +197,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": instances * BYTES_PER_INSTANCE,
                          "kernels_ms": {"part1": parts["part1"], "part2": parts["part2"], "bucket_count": parts["bucket"],
-                                        "bucket_compact": parts["seg_compact"], "table_init": float(np.mean(init_ms)),
+                                        "flagged_buckets": parts["seg_compact"], "table_init": float(np.mean(init_ms)),
                                         "table_to_arrays": parts["compact"], "hist": float(np.mean(hist_ms))}},
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -55,8 +55,10 @@ struct pb_ctx {
     // distinct (key,count) arrays of the last pb_count / pb_merge_end (device form of kmerFP)
     DevBuf dist_keys, dist_counts;      // u64[n*W], u32[n]
     int count_path = 0;                 // 1 = direct (v1), 2 = partitioned (v2)
-    DevBuf part_bucket1, part_bucket2, part_meta, part_out_counts, part_out_keys, part_segs;
+    DevBuf part_bucket1, part_bucket2, part_meta, part_spill;
     u64 sk_records = 0;            // super-k-mer records of the last counting pass (0 = other path)
+    u64 sk_flagged = 0, sk_extra_for = 0;
+    unsigned sk_bits = 0, sk_extra_bits = 0;       // bucket bits used; extra bits that an earlier pass over the same stream needed
 
     // owner exchange (X1)
     DevBuf exp_keys, exp_counts, merge_table;
@@ -188,7 +190,7 @@ void pb_destroy(pb_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     release(ctx->packed); release(ctx->nmask); release(ctx->table); release(ctx->d_hist); release(ctx->d_scalars);
     release(ctx->ret_keys); release(ctx->ret_counts); release(ctx->exp_keys); release(ctx->exp_counts); release(ctx->merge_table);
-    release(ctx->dist_keys); release(ctx->dist_counts); release(ctx->part_bucket1); release(ctx->part_bucket2); release(ctx->part_meta); release(ctx->part_out_counts); release(ctx->part_out_keys); release(ctx->part_segs);
+    release(ctx->dist_keys); release(ctx->dist_counts); release(ctx->part_bucket1); release(ctx->part_bucket2); release(ctx->part_meta); release(ctx->part_spill);
     release(ctx->index_table); release(ctx->nmask_cur); release(ctx->alive); release(ctx->d_read_start);
     release(ctx->contig_packed); release(ctx->contig_mask); release(ctx->ctable);
     release(ctx->chain_work); release(ctx->chain_rec); release(ctx->chain_seq);
@@ -379,191 +381,68 @@ static int count_direct(pb_ctx *ctx, unsigned k)
     return table_to_arrays<W>(ctx, std::min<u64>(ctx->n_instances, ctx->table_cap), false);
 }
 
-// v2: two-level hash partitioning + LDS-resident counting (k <= 32)
-static int count_partitioned(pb_ctx *ctx, unsigned k, bool *done)
-{
-    int rc;
-    *done = false;
-    const u64 windows = ctx->stream_len;          // upper bound on counted windows
-    unsigned logp = PB_BUCKET_CAP > 2048 ? 13 : 12;      // a bucket's LDS slot keeps the count in the low logp bits (count <= PB_BUCKET_CAP)
-    while (((u64)PB_BUCKET_MEAN << logp) < windows && logp < 20) ++logp;
-    if (const char *fl = getenv("PB_FORCE_LOGP")) {            // tests: exercise other digit widths on small inputs
-        const int v = atoi(fl);
-        if (v >= (PB_BUCKET_CAP > 2048 ? 13 : 12) && v <= 20 && ((u64)PB_BUCKET_MEAN << v) >= windows) logp = (unsigned)v;
-    }
-    if (((u64)PB_BUCKET_MEAN << logp) < windows) return PB_OK;          // too large for 2^20 buckets: caller uses v1
-    const int abl = getenv("PB_ABLATE") ? atoi(getenv("PB_ABLATE")) : 0;   // development: timing with parts of the kernels removed (results invalid)
-    PartParams p;
-    p.l1 = (logp + 1) / 2;
-    p.l2 = logp - p.l1;
-    // a sub-stream holds 1/PB_XCD of a bucket if blocks are dealt evenly over the XCDs (observed: round-robin); 1.5x margin,
-    // anything beyond goes through the fallback table
-    p.cap1 = ((windows >> p.l1) / PB_XCD) * 3 / 2 + 8192;
-    const u64 nb1 = (1ull << p.l1) * PB_XCD, nb2 = 1ull << logp;
-    if ((rc = ensure(ctx, ctx->part_bucket1, nb1 * p.cap1 * 8)) != PB_OK) return rc;
-    if ((rc = ensure(ctx, ctx->part_bucket2, nb2 * PB_BUCKET_CAP * 8)) != PB_OK) return rc;
-    if ((rc = ensure(ctx, ctx->part_meta, (nb1 + 2 * nb2) * 4)) != PB_OK) return rc;
-    p.bucket1 = (u64 *)ctx->part_bucket1.p;
-    p.bucket2 = (u64 *)ctx->part_bucket2.p;
-    p.cursor1 = (u32 *)ctx->part_meta.p;
-    p.cursor2 = p.cursor1 + nb1;
-    p.flag2 = p.cursor2 + nb2;
-    // fallback table (v1 representation) for flagged buckets
-    u64 fcap = 1ull << 20;
-    for (int attempt = 0; attempt < 10; ++attempt) {
-        if ((rc = ensure(ctx, ctx->table, fcap * 16)) != PB_OK) return rc;
-        ctx->table_cap = fcap;
-        p.fallback = TableView<1>{(u64 *)ctx->table.p, fcap - 1};
-        p.scalars = (u64 *)ctx->d_scalars.p;
-        HIPCHK(hipMemsetAsync(ctx->d_scalars.p, 0, 16 * 8, ctx->stream));
-        HIPCHK(hipMemsetAsync(ctx->part_meta.p, 0, (nb1 + 2 * nb2) * 4, ctx->stream));
-        {
-            StageTimer ti(ctx, "table_init");
-            table_init_kernel<1><<<grid_for(fcap * 2, 256, 256 * 32), 256, 0, ctx->stream>>>(p.fallback.slots, fcap);
-            if ((rc = ti.stop()) != PB_OK) return rc;
-        }
-        const u64 cap_out = std::max<u64>(windows, 1);
-        DevBuf &tmp_keys = ctx->part_bucket1;      // level-1 buckets are dead after part2: reuse them as the segmented output
-        DevBuf &tmp_counts = ctx->part_out_counts;
-        if ((rc = ensure(ctx, tmp_counts, cap_out * 4)) != PB_OK) return rc;
-        // per-bucket offsets: [bucket_base u64 nb2][dst_base u64 nb2][block sums u64 1024][n_occ u32 nb2]
-        if ((rc = ensure(ctx, ctx->part_segs, nb2 * 20 + 1024 * 8 + 64)) != PB_OK) return rc;
-        u64 *bucket_base = (u64 *)ctx->part_segs.p, *dst_base = bucket_base + nb2, *blk_sums = dst_base + nb2;
-        u32 *n_occ = (u32 *)(blk_sums + 1024);
-        HIPCHK(hipMemsetAsync(n_occ, 0, nb2 * 4, ctx->stream));
-        {
-            StageTimer t1(ctx, "part1");
-            const u64 n_tiles = (ctx->stream_len + PB_TILE - 1) / PB_TILE;
-#define PB_P1_ARGS (const u64 *)ctx->packed.p, cur_mask(ctx), ctx->stream_len, (ctx->stream_len + 63) / 64 + PB_STREAM_PAD_WORDS64, k, p
-            const dim3 g1(grid_for(n_tiles, 1, 256 * 8));
-            switch (abl & 3) {
-            case 0: part1_kernel<0><<<g1, PB_PART_THREADS, 0, ctx->stream>>>(PB_P1_ARGS); break;
-            case 1: part1_kernel<1><<<g1, PB_PART_THREADS, 0, ctx->stream>>>(PB_P1_ARGS); break;
-            default: part1_kernel<2><<<g1, PB_PART_THREADS, 0, ctx->stream>>>(PB_P1_ARGS); break;
-            }
-            HIPCHK(hipGetLastError());
-            if ((rc = t1.stop()) != PB_OK) return rc;
-        }
-        {
-            StageTimer t2(ctx, "part2");
-            const unsigned tiles_per_b1 = (unsigned)std::min<u64>((p.cap1 + PB_TILE - 1) / PB_TILE, 65535);
-            const dim3 g2(tiles_per_b1, (unsigned)nb1);                 // nb1 counts sub-streams
-            switch ((abl >> 2) & 3) {
-            case 0: part2_kernel<0><<<g2, PB_PART_THREADS, 0, ctx->stream>>>(p); break;
-            case 1: part2_kernel<1><<<g2, PB_PART_THREADS, 0, ctx->stream>>>(p); break;
-            default: part2_kernel<2><<<g2, PB_PART_THREADS, 0, ctx->stream>>>(p); break;
-            }
-            HIPCHK(hipGetLastError());
-            if ((rc = t2.stop()) != PB_OK) return rc;
-        }
-        const unsigned scan_blocks = (unsigned)(nb2 / 1024);
-        {
-            StageTimer t3(ctx, "bucket");
-            scan_local_kernel<<<scan_blocks, 256, 0, ctx->stream>>>(p.cursor2, PB_BUCKET_CAP, bucket_base, blk_sums);
-            scan_sums_kernel<<<1, 1024, 0, ctx->stream>>>(blk_sums, scan_blocks, (u64 *)ctx->d_scalars.p + 3);
-            scan_add_kernel<<<scan_blocks, 256, 0, ctx->stream>>>(bucket_base, blk_sums);
-#define PB_BC_ARGS p, (u64 *)tmp_keys.p, (u32 *)tmp_counts.p, bucket_base, n_occ
-            const dim3 g3(grid_for(nb2, 1, 256 * 64));
-            switch ((abl >> 4) & 3) {
-            case 0: bucket_count_kernel<0><<<g3, PB_BC_THREADS, 0, ctx->stream>>>(PB_BC_ARGS); break;
-            case 1: bucket_count_kernel<1><<<g3, PB_BC_THREADS, 0, ctx->stream>>>(PB_BC_ARGS); break;
-            case 2: bucket_count_kernel<2><<<g3, PB_BC_THREADS, 0, ctx->stream>>>(PB_BC_ARGS); break;
-            default: bucket_count_kernel<3><<<g3, PB_BC_THREADS, 0, ctx->stream>>>(PB_BC_ARGS); break;
-            }
-            HIPCHK(hipGetLastError());
-            if ((rc = t3.stop()) != PB_OK) return rc;
-        }
-        u64 sc[5];
-        {
-            StageTimer t4(ctx, "seg_compact");
-            scan_local_kernel<<<scan_blocks, 256, 0, ctx->stream>>>(n_occ, 0xFFFFFFFFu, dst_base, blk_sums);
-            scan_sums_kernel<<<1, 1024, 0, ctx->stream>>>(blk_sums, scan_blocks, (u64 *)ctx->d_scalars.p + 4);
-            scan_add_kernel<<<scan_blocks, 256, 0, ctx->stream>>>(dst_base, blk_sums);
-            HIPCHK(hipMemcpyAsync(sc, ctx->d_scalars.p, 40, hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(hipStreamSynchronize(ctx->stream));
-            if (sc[1] == 0) {
-                const u64 total = sc[4];
-                if ((rc = ensure(ctx, ctx->dist_keys, std::max<u64>(total + fcap, 1) * 8)) != PB_OK) return rc;
-                if ((rc = ensure(ctx, ctx->dist_counts, std::max<u64>(total + fcap, 1) * 4)) != PB_OK) return rc;
-                bucket_compact_kernel<<<grid_for(nb2 * 16, 256, 256 * 16), 256, 0, ctx->stream>>>(
-                    (const u64 *)tmp_keys.p, (const u32 *)tmp_counts.p, bucket_base, n_occ, dst_base, (unsigned)nb2, (u64 *)ctx->dist_keys.p,
-                    (u32 *)ctx->dist_counts.p);
-                HIPCHK(hipGetLastError());
-            }
-            if ((rc = t4.stop()) != PB_OK) return rc;
-        }
-        if (sc[1] == 0) {
-            ctx->n_instances = sc[0];
-            ctx->n_distinct = sc[4];
-            break;
-        }
-        fcap <<= 2;                     // the fallback table itself overflowed: retry with a larger one
-        if (attempt == 9) { ctx->err = "fallback table overflow"; return PB_ENOMEM; }
-    }
-    ctx->stage_ms["count"] = ctx->stage_ms["part1"] + ctx->stage_ms["part2"] + ctx->stage_ms["bucket"] + ctx->stage_ms["seg_compact"];
-    // records counted through the fallback table are appended
-    if ((rc = table_to_arrays<1>(ctx, ctx->table_cap, true)) != PB_OK) return rc;
-    *done = true;
-    return PB_OK;
-}
-
-// v3: super-k-mer records, two-level partition by minimizer bucket, LDS-resident counting (k <= 32)
+// v2: super-k-mer records, two-level partition by minimizer bucket, LDS-resident counting (k <= 32)
 static int count_superk(pb_ctx *ctx, unsigned k, bool *done)
 {
     int rc;
     *done = false;
-    const u64 windows = ctx->stream_len;          // upper bound on counted windows
+    // upper bound on counted windows: every read loses k - 1 positions and its separator
+    const u64 lost = (u64)k * ctx->n_reads;
+    const u64 windows = ctx->stream_len > lost + 4096 ? ctx->stream_len - lost : ctx->stream_len;
     SkParams p;
     p.abl = getenv("PB_ABLATE") ? atoi(getenv("PB_ABLATE")) : 0;
     p.k = k;
     p.m = k < SK_M ? k : SK_M;
     p.w = k - p.m + 1;
-    // ~12 K windows per final bucket: with sequencing-depth data that is 1-2 K distinct keys for a 4096-slot LDS table
-    p.B = 8;
-    while (((u64)12288 << p.B) < windows && p.B < 18) ++p.B;
+    // ~12 K windows per final bucket: with sequencing-depth data that is 1-2 K distinct keys for the 4096-slot LDS table.
+    // Low-coverage data has more distinct keys per window; the pass is then repeated with 4x the buckets (see below) and
+    // the context remembers what worked.
+    unsigned B = 8;
+    while (((u64)12288 << B) < windows && B < 18) ++B;
+    if (ctx->sk_extra_bits && ctx->sk_extra_for == windows) B = std::min(18u, B + ctx->sk_extra_bits);
+    bool forced_b = false;
     if (const char *fb = getenv("PB_FORCE_SKB")) {            // tests: other bucket counts on small inputs
         const int v = atoi(fb);
-        if (v >= 2 && v <= 18) p.B = (unsigned)v;
+        if (v >= 2 && v <= 18) { B = (unsigned)v; forced_b = true; }
     }
-    p.l1 = p.B / 2;
-    p.l2 = p.B - p.l1;
-    const int max_bases = (int)(123 - p.B) / 2;                 // 128 bits - 5 (length) - B (bucket), two bits per base
-    int L = max_bases - (int)k + 1;
-    if (L > 31) L = 31;
-    if (L < 1) return PB_OK;
-    p.L = (unsigned)L;
-    // expected windows per record: a new minimizer every (w+1)/2 windows, a forced start every L
-    const double avg_len = 1.0 / (2.0 / (p.w + 1.0) + 1.0 / p.L);
-    const double est_rec = (double)windows / avg_len;
-    const u64 nb1 = (1ull << p.l1) * PB_XCD, nb2 = 1ull << p.B;
-    p.cap1 = (u64)(est_rec / (double)nb1 * 1.5) + 4096;
-    p.cap2 = (u32)std::min<double>(est_rec / (double)nb2 * 2.0 + 256.0, 1e9);
-    if ((rc = ensure(ctx, ctx->part_bucket1, nb1 * p.cap1 * sizeof(SkRec))) != PB_OK) return rc;
-    if ((rc = ensure(ctx, ctx->part_bucket2, nb2 * (u64)p.cap2 * sizeof(SkRec))) != PB_OK) return rc;
-    if ((rc = ensure(ctx, ctx->part_meta, (nb1 + 2 * nb2) * 4)) != PB_OK) return rc;
-    p.bucket1 = (SkRec *)ctx->part_bucket1.p;
-    p.bucket2 = (SkRec *)ctx->part_bucket2.p;
-    p.cursor1 = (u32 *)ctx->part_meta.p;
-    p.cursor2 = p.cursor1 + nb1;
-    p.flag2 = p.cursor2 + nb2;
-    // segmented output: SK_SLOTS entries per bucket; [bucket_base u64 nb2][dst_base u64 nb2][block sums u64 1024][n_occ u32 nb2]
-    DevBuf &tmp_keys = ctx->part_out_keys;
-    DevBuf &tmp_counts = ctx->part_out_counts;
-    if ((rc = ensure(ctx, tmp_keys, nb2 * SK_SLOTS * 8)) != PB_OK) return rc;
-    if ((rc = ensure(ctx, tmp_counts, nb2 * SK_SLOTS * 4)) != PB_OK) return rc;
-    const u64 nb2s = (nb2 + 1023) / 1024 * 1024;               // the scan kernels work on multiples of 1024 entries
-    if ((rc = ensure(ctx, ctx->part_segs, nb2s * 20 + 1024 * 8 + 64)) != PB_OK) return rc;
-    u64 *bucket_base = (u64 *)ctx->part_segs.p, *dst_base = bucket_base + nb2s, *blk_sums = dst_base + nb2s;
-    u32 *n_occ = (u32 *)(blk_sums + 1024);
     u64 fcap = 1ull << 20;
-    for (int attempt = 0; attempt < 10; ++attempt) {
+    for (int attempt = 0; attempt < 12; ++attempt) {
+        p.B = B;
+        p.l1 = B / 2;
+        p.l2 = B - p.l1;
+        const int max_bases = (int)(123 - B) / 2;                 // 128 bits - 5 (length) - B (bucket), two bits per base
+        int L = max_bases - (int)k + 1;
+        if (L > SK_LCAP) L = SK_LCAP;
+        if (const char *lc = getenv("PB_SK_LCAP")) { const int v = atoi(lc); if (v >= 1 && v < 32 && v <= max_bases - (int)k + 1) L = v; }
+        if (L < 1) return PB_OK;
+        p.L = (unsigned)L;
+        // expected windows per record: a new minimizer every (w+1)/2 windows, a forced start every L
+        const double avg_len = 1.0 / (2.0 / (p.w + 1.0) + 1.0 / p.L);
+        const double est_rec = (double)windows / avg_len;
+        const u64 nb1 = (1ull << p.l1) * PB_XCD, nb2 = 1ull << B;
+        p.cap1 = (u64)(est_rec / (double)nb1 * 1.5) + 4096;
+        p.cap2 = (u32)std::min<double>(est_rec / (double)nb2 * 3.0 + 256.0, 1e9);   // minimizer sites are few per bucket: sizes vary a lot
+        if ((rc = ensure(ctx, ctx->part_bucket1, nb1 * p.cap1 * sizeof(SkRec))) != PB_OK) return rc;
+        if ((rc = ensure(ctx, ctx->part_bucket2, nb2 * (u64)p.cap2 * sizeof(SkRec))) != PB_OK) return rc;
+        if ((rc = ensure(ctx, ctx->part_meta, (nb1 + 2 * nb2) * 4)) != PB_OK) return rc;
+        p.spill_cap = std::max<u64>((u64)(est_rec / 16), 1ull << 16);
+        if ((rc = ensure(ctx, ctx->part_spill, p.spill_cap * sizeof(SkRec))) != PB_OK) return rc;
+        p.spill = (SkRec *)ctx->part_spill.p;
+        p.bucket1 = (SkRec *)ctx->part_bucket1.p;
+        p.bucket2 = (SkRec *)ctx->part_bucket2.p;
+        p.cursor1 = (u32 *)ctx->part_meta.p;
+        p.cursor2 = p.cursor1 + nb1;
+        p.flag2 = p.cursor2 + nb2;
+        // the distinct arrays are written in place: room for every bucket's table full, plus the fallback table's records
+        const u64 out_cap = std::min<u64>(std::max<u64>(ctx->stream_len, 1), nb2 * (u64)SK_SLOT_LIMIT);
+        if ((rc = ensure(ctx, ctx->dist_keys, (out_cap + fcap) * 8)) != PB_OK) return rc;
+        if ((rc = ensure(ctx, ctx->dist_counts, (out_cap + fcap) * 4)) != PB_OK) return rc;
         if ((rc = ensure(ctx, ctx->table, fcap * 16)) != PB_OK) return rc;
         ctx->table_cap = fcap;
         p.fallback = TableView<1>{(u64 *)ctx->table.p, fcap - 1};
         p.scalars = (u64 *)ctx->d_scalars.p;
         HIPCHK(hipMemsetAsync(ctx->d_scalars.p, 0, 16 * 8, ctx->stream));
         HIPCHK(hipMemsetAsync(ctx->part_meta.p, 0, (nb1 + 2 * nb2) * 4, ctx->stream));
-        HIPCHK(hipMemsetAsync(n_occ, 0, nb2s * 4, ctx->stream));
         {
             StageTimer ti(ctx, "table_init");
             table_init_kernel<1><<<grid_for(fcap * 2, 256, 256 * 32), 256, 0, ctx->stream>>>(p.fallback.slots, fcap);
@@ -586,41 +465,46 @@ static int count_superk(pb_ctx *ctx, unsigned k, bool *done)
             HIPCHK(hipGetLastError());
             if ((rc = t2.stop()) != PB_OK) return rc;
         }
+        u64 sc[9];
         {
             StageTimer t3(ctx, "bucket");
-            sk_bucket_kernel<<<grid_for(nb2, 1, 256 * 16), SK_BC_THREADS, 0, ctx->stream>>>(p, (u64 *)tmp_keys.p, (u32 *)tmp_counts.p, n_occ);
+            sk_bucket_kernel<<<grid_for(nb2, 1, 256 * 16), SK_ROLL_THREADS, 0, ctx->stream>>>(p, (u64 *)ctx->dist_keys.p, (u32 *)ctx->dist_counts.p, out_cap);
             HIPCHK(hipGetLastError());
-            if ((rc = t3.stop()) != PB_OK) return rc;
+            HIPCHK(hipMemcpyAsync(sc, ctx->d_scalars.p, 72, hipMemcpyDeviceToHost, ctx->stream));
+            if ((rc = t3.stop()) != PB_OK) return rc;              // synchronises the stream
         }
-        u64 sc[8];
-        {
-            StageTimer t4(ctx, "seg_compact");
-            const unsigned scan_blocks = (unsigned)(nb2s / 1024);
-            sk_bucket_base_kernel<<<(unsigned)((nb2 + 255) / 256), 256, 0, ctx->stream>>>(bucket_base, (unsigned)nb2);
-            scan_local_kernel<<<scan_blocks, 256, 0, ctx->stream>>>(n_occ, 0xFFFFFFFFu, dst_base, blk_sums);
-            scan_sums_kernel<<<1, 1024, 0, ctx->stream>>>(blk_sums, scan_blocks, (u64 *)ctx->d_scalars.p + 4);
-            scan_add_kernel<<<scan_blocks, 256, 0, ctx->stream>>>(dst_base, blk_sums);
-            HIPCHK(hipMemcpyAsync(sc, ctx->d_scalars.p, 64, hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(hipStreamSynchronize(ctx->stream));
-            if (sc[1] == 0) {
-                const u64 total = sc[4];
-                if ((rc = ensure(ctx, ctx->dist_keys, std::max<u64>(total + fcap, 1) * 8)) != PB_OK) return rc;
-                if ((rc = ensure(ctx, ctx->dist_counts, std::max<u64>(total + fcap, 1) * 4)) != PB_OK) return rc;
-                bucket_compact_kernel<<<grid_for(nb2 * 16, 256, 256 * 16), 256, 0, ctx->stream>>>(
-                    (const u64 *)tmp_keys.p, (const u32 *)tmp_counts.p, bucket_base, n_occ, dst_base, (unsigned)nb2, (u64 *)ctx->dist_keys.p,
-                    (u32 *)ctx->dist_counts.p);
-                HIPCHK(hipGetLastError());
-            }
+        // sc[7] buckets had more distinct keys than an LDS table holds.  Many of them: the input is not the high-coverage kind
+        // the bucket count was chosen for -- repeat with 4x the buckets rather than push a large share through the global table.
+        if (!forced_b && sc[7] > nb2 / 64 && B < 18) {
+            B = std::min(18u, B + 2);
+            ctx->sk_extra_bits += 2;
+            ctx->sk_extra_for = windows;
+            continue;
+        }
+        if (!forced_b && sc[7] > nb2 / 4) return PB_OK;            // still mostly overflowing at 2^18 buckets: the direct path takes it
+        ctx->stage_ms["seg_compact"] = 0.f;
+        if (sc[7] + sc[8] > 0) {
+            StageTimer t4(ctx, "seg_compact");                     // (stage name kept for bench.py: flagged buckets through the global table)
+            sk_flagged_kernel<<<dim3(grid_for(nb2, 1, 1024), 16), 256, 0, ctx->stream>>>(p);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(sc, ctx->d_scalars.p, 72, hipMemcpyDeviceToHost, ctx->stream));
             if ((rc = t4.stop()) != PB_OK) return rc;
         }
         if (sc[1] == 0) {
             ctx->n_instances = sc[0];
             ctx->n_distinct = sc[4];
             ctx->sk_records = sc[6];
+            ctx->sk_bits = B;
+            ctx->sk_flagged = sc[7];
+            ctx->stage_ms["sk_bucket_bits"] = (float)B;                    // pass statistics, read like the stage times
+            ctx->stage_ms["sk_flagged_buckets"] = (float)sc[7];
+            ctx->stage_ms["sk_spilled_records"] = (float)sc[8];
+            ctx->stage_ms["sk_records_per_1k_windows"] = sc[0] ? (float)(1000.0 * (double)sc[6] / (double)sc[0]) : 0.f;
             break;
         }
-        fcap <<= 2;                     // the fallback table itself overflowed: retry with a larger one
-        if (attempt == 9) { ctx->err = "fallback table overflow"; return PB_ENOMEM; }
+        if (sc[8] > p.spill_cap) return PB_OK;   // a few minimizers carry most of the input (tiny k, low-complexity reads): the direct path takes it
+        fcap <<= 2;                     // the fallback table overflowed: retry with a larger one
+        if (attempt == 11) { ctx->err = "fallback table overflow"; return PB_ENOMEM; }
     }
     ctx->stage_ms["count"] = ctx->stage_ms["part1"] + ctx->stage_ms["part2"] + ctx->stage_ms["bucket"] + ctx->stage_ms["seg_compact"];
     if ((rc = table_to_arrays<1>(ctx, ctx->table_cap, true)) != PB_OK) return rc;
@@ -642,15 +526,12 @@ int pb_count(pb_ctx *ctx, unsigned k, uint64_t *occ_hist, uint64_t *max_occ, uin
     int rc;
     if ((rc = ensure(ctx, ctx->d_scalars, 16 * 8)) != PB_OK) return rc;
     bool done = false;
-    const char *force = getenv("PB_COUNT_PATH");       // "direct" | "partitioned" (development / A-B runs)
-    const bool want_part = ctx->W == 1 && ctx->stream_len >= k &&
-                           (force ? strcmp(force, "partitioned") == 0 : ctx->stream_len >= (1ull << 22));
+    const char *force = getenv("PB_COUNT_PATH");       // "direct" | "superk" (development / A-B runs, tests on small inputs)
+    const bool want_sk = ctx->W == 1 && ctx->stream_len >= k &&
+                         (force ? strcmp(force, "superk") == 0 || strcmp(force, "partitioned") == 0 : ctx->stream_len >= (1ull << 22));
     ctx->sk_records = 0;
-    if (ctx->W == 1 && ctx->stream_len >= k && force && strcmp(force, "superk") == 0) {
+    if (want_sk) {
         if ((rc = count_superk(ctx, k, &done)) != PB_OK) return rc;
-    }
-    if (!done && want_part && !(force && strcmp(force, "direct") == 0)) {
-        if ((rc = count_partitioned(ctx, k, &done)) != PB_OK) return rc;
     }
     if (!done) {
         switch (ctx->W) {

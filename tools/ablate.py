@@ -43,7 +43,8 @@ def main():
             t0 = time.perf_counter()
             g.make_kmer_read_distribution(32)
             wall = (time.perf_counter() - t0) * 1e3
-        print(f"{cfg:40s} " + " ".join(f"{s}={g.kernel_ms(s):7.3f}" for s in stages) + f" wall={wall:7.2f} distinct={g.n_distinct}", flush=True)
+        extra = " ".join(f"{s[3:]}={g.kernel_ms(s):g}" for s in ("sk_bucket_bits", "sk_flagged_buckets", "sk_records_per_1k_windows"))
+        print(f"{cfg:40s} " + " ".join(f"{s}={g.kernel_ms(s):7.3f}" for s in stages) + f" wall={wall:7.2f} distinct={g.n_distinct} {extra}", flush=True)
         for k, _ in sets:
             del os.environ[k]
 
