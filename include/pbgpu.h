@@ -105,7 +105,7 @@ int pb_merge_end(pb_ctx *ctx, uint64_t *occ_hist, uint64_t *max_occ, uint64_t *n
  *                 the reverse complement of its canonical key; 0xFFFFFFFF otherwise.
  * With these two arrays the host replays the reference's DFS (visiting order, strands, cut points of cycles) in O(n)
  * array steps instead of hash probes; see platanus_b_amd/host/device_graph.hpp. */
-int pb_graph_adjacency(pb_ctx *ctx, uint8_t *adj, uint32_t *nbr);
+int pb_graph_adjacency(pb_ctx *ctx, uint8_t *adj, uint32_t *nbr);   /* adj = nbr = NULL: keep the arrays on the device only */
 
 /* K7 chain compaction (the unitig walk of graph.h:406-542 as node-parallel kernels: pointer-jumping list ranking over
  * the adjacency arrays, per-chain coverage sum, sequence gather).  Call after pb_graph_adjacency.
@@ -119,6 +119,24 @@ int pb_graph_adjacency(pb_ctx *ctx, uint8_t *adj, uint32_t *nbr);
 int pb_graph_chains(pb_ctx *ctx, uint64_t *n_chains, uint64_t *seq_words);
 int pb_graph_fetch_chains(pb_ctx *ctx, uint32_t *chain_of, uint8_t *orient, uint32_t *len, uint64_t *sum, uint32_t *end_a,
                           uint32_t *end_b, uint64_t *seq_woff, uint64_t *seq);
+
+/* Compact form of the same hand-over (what `platanus_b assemble` uses): the reference's DFS (graph.h:330-579) only ever
+ * lands on junction k-mers, k-mers on cycles / hairpins and the two end k-mers of a simple chain, so only those "nodes" and
+ * the per-chain records cross PCIe; the retained keys and the per-k-mer arrays (8W + 15 bytes per k-mer) stay on the device.
+ * Call after pb_graph_chains.  Per node s (arbitrary order):
+ *   idx[s]          index of the k-mer in the retained set
+ *   meta[s]         adj | orient << 8 | count << 16        (adj, orient as above)
+ *   chain[s]        chain id | 0xFFFFFFFF junction | 0xFFFFFFFE cycle / hairpin
+ *   nbr[2s], [2s+1] as pb_graph_adjacency
+ *   nb8[8s + b]     junctions only: (index << 1 | flip) of the successor with base b (b < 4) / predecessor with base b - 4 of
+ *                   the canonical key, 0xFFFFFFFF if absent (the eight findValue probes of graph.h:352-380 with their results)
+ *   keys[s * W ..]  canonical key
+ * Per chain, additionally to pb_graph_fetch_chains: root[c] = (smallest member index << 1) | orient of that member, i.e.
+ * where the reference's ascending-key root loop first meets the chain. */
+int pb_graph_nodes(pb_ctx *ctx, uint64_t *n_nodes);
+int pb_graph_fetch_nodes(pb_ctx *ctx, uint32_t *idx, uint32_t *meta, uint32_t *chain, uint32_t *nbr, uint32_t *nb8, uint64_t *keys);
+int pb_graph_fetch_chain_records(pb_ctx *ctx, uint32_t *len, uint64_t *sum, uint32_t *end_a, uint32_t *end_b, uint32_t *root,
+                                 uint64_t *seq_woff, uint64_t *seq);
 
 /* ---- multi-k rounds (assemble.cpp:392-498) ------------------------------------------------------------------- */
 /* saveEdgeKmer + pickupReadMatchedEdgeKmer (graph.h:1877-1939, counter.h:869-910): keep a read iff one of its N-free

@@ -57,7 +57,7 @@ struct pb_ctx {
     int count_path = 0;                 // 1 = direct (v1), 2 = partitioned (v2)
     DevBuf part_bucket1, part_bucket2, part_meta, part_spill;
     u64 sk_records = 0;            // super-k-mer records of the last counting pass (0 = other path)
-    u64 sk_flagged = 0, sk_extra_for = 0;
+    u64 sk_flagged = 0, sk_spilled = 0, sk_extra_for = 0;
     unsigned sk_bits = 0, sk_extra_bits = 0;       // bucket bits used; extra bits that an earlier pass over the same stream needed
 
     // owner exchange (X1)
@@ -67,6 +67,9 @@ struct pb_ctx {
 
     // graph stage / multi-k rounds
     DevBuf index_table;                 // retained key -> index + 1
+    u64 index_table_cap = 0;
+    DevBuf node_mark, node_idx, node_rec; // compact export of the k-mers the host replay touches
+    u64 n_nodes = 0, node_cap_hint = 0;
     DevBuf nmask_cur, alive, d_read_start;   // filtered read set: working mask copy, per-read flag, stream starts
     std::vector<u64> read_start;        // host copy: stream position of every read + final sentinel (= stream_len)
     size_t read_start_dev_n = 0;
@@ -191,7 +194,7 @@ void pb_destroy(pb_ctx *ctx)
     release(ctx->packed); release(ctx->nmask); release(ctx->table); release(ctx->d_hist); release(ctx->d_scalars);
     release(ctx->ret_keys); release(ctx->ret_counts); release(ctx->exp_keys); release(ctx->exp_counts); release(ctx->merge_table);
     release(ctx->dist_keys); release(ctx->dist_counts); release(ctx->part_bucket1); release(ctx->part_bucket2); release(ctx->part_meta); release(ctx->part_spill);
-    release(ctx->index_table); release(ctx->nmask_cur); release(ctx->alive); release(ctx->d_read_start);
+    release(ctx->index_table); release(ctx->node_mark); release(ctx->node_idx); release(ctx->node_rec); release(ctx->nmask_cur); release(ctx->alive); release(ctx->d_read_start);
     release(ctx->contig_packed); release(ctx->contig_mask); release(ctx->ctable);
     release(ctx->chain_work); release(ctx->chain_rec); release(ctx->chain_seq);
     release(ctx->layout_work); release(ctx->layout_slots); release(ctx->layout_out); release(ctx->scan_sums); release(ctx->slot_blk);
@@ -459,8 +462,8 @@ static int count_superk(pb_ctx *ctx, unsigned k, bool *done)
         {
             StageTimer t2(ctx, "part2");
             // a few blocks per sub-stream, each striding over its tiles (most of cap1 is head-room: one block per tile would be mostly empty blocks)
-            const u64 exp_tiles = (u64)(est_rec / (double)nb1) / SK_RCAP + 1;
-            const unsigned blocks_per_sub = (unsigned)std::min<u64>(std::max<u64>(exp_tiles / 3, 1), 64);
+            const u64 exp_tiles = (u64)(est_rec / (double)nb1) / SK2_RCAP + 1;
+            const unsigned blocks_per_sub = (unsigned)std::min<u64>(std::max<u64>(exp_tiles / 4, 1), 64);
             sk_part2_kernel<<<dim3(blocks_per_sub, (unsigned)nb1), SK_THREADS, 0, ctx->stream>>>(p);
             HIPCHK(hipGetLastError());
             if ((rc = t2.stop()) != PB_OK) return rc;
@@ -496,6 +499,7 @@ static int count_superk(pb_ctx *ctx, unsigned k, bool *done)
             ctx->sk_records = sc[6];
             ctx->sk_bits = B;
             ctx->sk_flagged = sc[7];
+            ctx->sk_spilled = sc[8];
             ctx->stage_ms["sk_bucket_bits"] = (float)B;                    // pass statistics, read like the stage times
             ctx->stage_ms["sk_flagged_buckets"] = (float)sc[7];
             ctx->stage_ms["sk_spilled_records"] = (float)sc[8];
@@ -507,7 +511,10 @@ static int count_superk(pb_ctx *ctx, unsigned k, bool *done)
         if (attempt == 11) { ctx->err = "fallback table overflow"; return PB_ENOMEM; }
     }
     ctx->stage_ms["count"] = ctx->stage_ms["part1"] + ctx->stage_ms["part2"] + ctx->stage_ms["bucket"] + ctx->stage_ms["seg_compact"];
-    if ((rc = table_to_arrays<1>(ctx, ctx->table_cap, true)) != PB_OK) return rc;
+    ctx->stage_ms["compact"] = 0.f;
+    if (ctx->sk_flagged + ctx->sk_spilled > 0) {                    // otherwise nothing went into the global table
+        if ((rc = table_to_arrays<1>(ctx, ctx->table_cap, true)) != PB_OK) return rc;
+    }
     *done = true;
     return PB_OK;
 }

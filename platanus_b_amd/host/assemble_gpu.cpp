@@ -84,6 +84,34 @@ struct Driver {
             Tick t("retain+sort (device)");
             chk(pb_retain(ctx, (unsigned)min_occ, &n));
         }
+        Graph<W> &g = graph<W>();
+        g.set_k(kk);
+        if (!getenv("PB_GRAPH_FETCH")) {
+            // compact hand-over: adjacency and chain arrays stay on the device, only the nodes the DFS can land on come back
+            NodeSet<W> nd;
+            ChainRecords cr;
+            nd.k = kk;
+            {
+                Tick t("adjacency (device)");
+                log("connecting kmers...");
+                chk(pb_graph_adjacency(ctx, nullptr, nullptr));
+            }
+            {
+                Tick t("chain compaction + node export (device + D2H)");
+                u64 nc = 0, words = 0, nn = 0;
+                chk(pb_graph_chains(ctx, &nc, &words));
+                chk(pb_graph_nodes(ctx, &nn));
+                cr.len.resize(nc); cr.end_a.resize(nc); cr.end_b.resize(nc); cr.root.resize(nc); cr.sum.resize(nc); cr.seq_woff.resize(nc); cr.seq.resize(words);
+                chk(pb_graph_fetch_chain_records(ctx, cr.len.data(), cr.sum.data(), cr.end_a.data(), cr.end_b.data(), cr.root.data(), cr.seq_woff.data(),
+                                                 cr.seq.data()));
+                nd.idx.resize(nn); nd.meta.resize(nn); nd.chain.resize(nn); nd.nbr.resize(2 * nn); nd.nb8.resize(8 * nn); nd.keys.resize(nn * W);
+                chk(pb_graph_fetch_nodes(ctx, nd.idx.data(), nd.meta.data(), nd.chain.data(), nd.nbr.data(), nd.nb8.data(), nd.keys.data()));
+            }
+            Tick t("DFS replay, chain level (host)");
+            make_initial_from_nodes(g, nd, cr);
+            return;
+        }
+        // development / A-B: the full per-k-mer arrays on the host (PB_GRAPH_FETCH=full, PB_NO_CHAINS=1 for the k-mer-level replay)
         {
             Tick t("fetch retained + adjacency (device + D2H)");
             keys.resize(n * W); counts.resize(n); adj.resize(n); nbr.resize(2 * n);
@@ -93,8 +121,6 @@ struct Driver {
         }
         DeviceGraphInput<W> in;
         in.k = kk; in.n = n; in.keys = keys.data(); in.counts = counts.data(); in.adj = adj.data(); in.nbr = nbr.data();
-        Graph<W> &g = graph<W>();
-        g.set_k(kk);
         if (getenv("PB_NO_CHAINS")) {                 // development switch: k-mer-level replay of the DFS
             Tick t("DFS replay, k-mer level (host)");
             make_initial_from_device(g, in);

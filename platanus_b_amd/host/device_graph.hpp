@@ -338,3 +338,215 @@ void make_initial_from_chains(Graph<W> &gr, const DeviceGraphInput<W> &in, const
 }
 
 } // namespace pbh
+
+// ---- replay from the compact hand-over (pb_graph_nodes / pb_graph_fetch_chain_records) -----------------------------------
+// Same DFS as make_initial_from_chains, but everything it reads comes from two small tables: the "nodes" (junction k-mers,
+// k-mers on cycles / hairpins, and the end k-mers of the simple chains -- the only k-mers the DFS can land on) and the
+// per-chain records.  The root loop of the reference (ascending key order over all k-mers, graph.h:330-341) becomes a merge
+// of the nodes with the chains' smallest members (root[c]): an interior k-mer of a chain is only ever a root through that.
+namespace pbh {
+
+template <int W>
+struct NodeSet {
+    unsigned k = 0;
+    std::vector<uint32_t> idx, meta, chain, nbr, nb8;   // as fetched; sort() orders everything by idx
+    std::vector<u64> keys;
+    u64 size() const { return idx.size(); }
+
+    void sort()
+    {
+        const u64 n = idx.size();
+        std::vector<uint32_t> order(n);
+        for (u64 i = 0; i < n; ++i) order[i] = (uint32_t)i;
+        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return idx[a] < idx[b]; });
+        std::vector<uint32_t> i2(n), m2(n), c2(n), n2(2 * n), b2(8 * n);
+        std::vector<u64> k2(n * W);
+        for (u64 s = 0; s < n; ++s) {
+            const u64 o = order[s];
+            i2[s] = idx[o]; m2[s] = meta[o]; c2[s] = chain[o];
+            n2[2 * s] = nbr[2 * o]; n2[2 * s + 1] = nbr[2 * o + 1];
+            for (int b = 0; b < 8; ++b) b2[8 * s + b] = nb8[8 * o + b];
+            for (int w = 0; w < W; ++w) k2[s * W + w] = keys[o * W + w];
+        }
+        idx.swap(i2); meta.swap(m2); chain.swap(c2); nbr.swap(n2); nb8.swap(b2); keys.swap(k2);
+    }
+    u64 slot_of(u64 i) const { return (u64)(std::lower_bound(idx.begin(), idx.end(), (uint32_t)i) - idx.begin()); }   // i is a node by construction
+    unsigned adj(u64 s) const { return meta[s] & 0xFFu; }
+    unsigned orient(u64 s) const { return (meta[s] >> 8) & 1u; }
+    unsigned count(u64 s) const { return meta[s] >> 16; }
+    Key<W> oriented(u64 s, unsigned f) const
+    {
+        Key<W> c;
+        for (int w = 0; w < W; ++w) c.w[w] = keys[s * W + w];
+        return f ? revcomp(c, k) : c;
+    }
+    unsigned rflags(u64 s, unsigned f) const { return f ? rev4(adj(s) >> 4) : (adj(s) & 15u); }
+    unsigned lflags(u64 s, unsigned f) const { return f ? rev4(adj(s) & 15u) : (adj(s) >> 4); }
+    void right_of(u64 s, unsigned f, u64 &j, unsigned &g) const { const uint32_t v = f ? nbr[2 * s + 1] : nbr[2 * s]; j = v >> 1; g = (v & 1u) ^ f; }
+    void left_of(u64 s, unsigned f, u64 &j, unsigned &g) const { const uint32_t v = f ? nbr[2 * s] : nbr[2 * s + 1]; j = v >> 1; g = (v & 1u) ^ f; }
+    // junctions: successor / predecessor with base b of the oriented k-mer (s,f).  succ(rc(K), b) = rc(pred(K, 3-b)).
+    void succ_of(u64 s, unsigned f, unsigned b, u64 &j, unsigned &g) const
+    {
+        const uint32_t e = f ? nb8[8 * s + 4 + (3 - b)] : nb8[8 * s + b];
+        j = e >> 1; g = (e & 1u) ^ f;
+    }
+    void pred_of(u64 s, unsigned f, unsigned b, u64 &j, unsigned &g) const
+    {
+        const uint32_t e = f ? nb8[8 * s + (3 - b)] : nb8[8 * s + 4 + b];
+        j = e >> 1; g = (e & 1u) ^ f;
+    }
+};
+
+struct ChainRecords {
+    std::vector<uint32_t> len, end_a, end_b, root;
+    std::vector<u64> sum, seq_woff, seq;
+    u64 size() const { return len.size(); }
+};
+
+template <int W>
+void make_initial_from_nodes(Graph<W> &gr, NodeSet<W> &nd, const ChainRecords &cs)
+{
+    typedef Key<W> K;
+    const unsigned k = nd.k;
+    gr.junctions.clear();
+    gr.left.clear();
+    gr.right.clear();
+    nd.sort();
+    const u64 nn = nd.size(), nc = cs.size();
+    std::vector<uint8_t> visited(nn, 0), chain_done(nc, 0);
+    std::vector<uint32_t> by_root(nc);
+    for (u64 c = 0; c < nc; ++c) by_root[c] = (uint32_t)c;
+    std::sort(by_root.begin(), by_root.end(), [&](uint32_t a, uint32_t b) { return cs.root[a] < cs.root[b]; });
+    struct Ori { u64 i; unsigned f; };
+    std::vector<Ori> stack;
+    std::vector<unsigned char> lseq, rseq;
+    std::vector<u64> rc_buf;
+    auto is_visited_slot = [&](u64 s) -> bool {
+        const uint32_t c = nd.chain[s];
+        return c < CHAIN_COMPLEX ? chain_done[c] != 0 : visited[s] != 0;
+    };
+    // a whole simple chain becomes one Straight; `aligned`: it is entered pointing along A -> B
+    auto take_chain = [&](uint32_t c, bool aligned) {
+        chain_done[c] = 1;
+        const u64 len = cs.len[c], ls = len + k - 1;
+        const Ori ea{cs.end_a[c] >> 1, cs.end_a[c] & 1u}, eb{cs.end_b[c] >> 1, cs.end_b[c] & 1u};
+        const Ori le = aligned ? ea : Ori{eb.i, eb.f ^ 1u};
+        const Ori re = aligned ? eb : Ori{ea.i, ea.f ^ 1u};
+        const u64 sl = nd.slot_of(le.i), sr = nd.slot_of(re.i);
+        const unsigned lfl = nd.lflags(sl, le.f), rfl = nd.rflags(sr, re.f);
+        if (lfl != 0) { Ori v; nd.left_of(sl, le.f, v.i, v.f); stack.push_back(v); }
+        if (rfl != 0) { Ori v; nd.right_of(sr, re.f, v.i, v.f); stack.push_back(v); }
+        Straight st;
+        st.length = len;
+        const u64 nw = (ls + 31) / 32;
+        const u64 *src = cs.seq.data() + cs.seq_woff[c];
+        if (aligned) st.seq.assign(src, src + nw);
+        else { revcomp_packed(src, ls, rc_buf); st.seq = rc_buf; }
+        st.seq.resize((len + k + 31) / 32, 0);                // binstr_t(length + k) word count (graph.h:559)
+        st.coverage = (u16)(static_cast<double>(cs.sum[c]) / static_cast<double>(len) + 0.5);
+        st.out = (uint8_t)((lfl << 4) | rfl);
+        gr.insert_straight(st);
+    };
+    auto run_stack = [&]() {
+        while (!stack.empty()) {
+            const Ori s = stack.back();
+            stack.pop_back();
+            const u64 ss = nd.slot_of(s.i);
+            if (is_visited_slot(ss)) continue;
+            const uint32_t c = nd.chain[ss];
+            if (c < CHAIN_COMPLEX) { take_chain(c, nd.orient(ss) == s.f); continue; }
+            visited[ss] = 1;
+            u64 sum = nd.count(ss);
+            unsigned lfl = nd.lflags(ss, s.f), rfl = nd.rflags(ss, s.f);
+            const K start = nd.oriented(ss, s.f);
+            if (c == CHAIN_JUNCTION) {                                            // graph.h:383-404
+                for (unsigned b = 0; b < 4; ++b) {
+                    Ori o;
+                    if (rfl & (1u << b)) { nd.succ_of(ss, s.f, b, o.i, o.f); stack.push_back(o); }
+                    if (lfl & (1u << b)) { nd.pred_of(ss, s.f, b, o.i, o.f); stack.push_back(o); }
+                }
+                Junction j;
+                j.coverage = (u16)sum;
+                j.out = (uint8_t)((lfl << 4) | rfl);
+                gr.junctions[start] = j;
+                continue;
+            }
+            // ---- k-mer on a cycle / hairpin / self loop: the reference's walk, k-mer by k-mer ----
+            lseq.clear();
+            rseq.clear();
+            if (lfl) lseq.push_back((unsigned char)flag2base(lfl));
+            if (rfl) rseq.push_back((unsigned char)flag2base(rfl));
+            Ori rstop = s, lstop = s;
+            if (!rseq.empty()) {
+                Ori v;
+                nd.right_of(ss, s.f, v.i, v.f);
+                while (true) {
+                    rstop = v;
+                    const u64 sv = nd.slot_of(v.i);
+                    if (flag_count(nd.lflags(sv, v.f)) > 1 || is_visited_slot(sv)) { rfl = 1u << rseq.back(); rseq.pop_back(); break; }
+                    const unsigned vr = nd.rflags(sv, v.f);
+                    if (vr == 0) { rfl = 0; sum += nd.count(sv); visited[sv] = 1; break; }
+                    else if (flag_count(vr) > 1) { rfl = 1u << rseq.back(); rseq.pop_back(); break; }
+                    rfl = vr;
+                    rseq.push_back((unsigned char)flag2base(vr));
+                    sum += nd.count(sv);
+                    visited[sv] = 1;
+                    Ori nx;
+                    nd.right_of(sv, v.f, nx.i, nx.f);
+                    v = nx;
+                }
+            }
+            if (!lseq.empty()) {
+                Ori v;
+                nd.left_of(ss, s.f, v.i, v.f);
+                while (true) {
+                    lstop = v;
+                    const u64 sv = nd.slot_of(v.i);
+                    if (flag_count(nd.rflags(sv, v.f)) > 1 || is_visited_slot(sv)) { lfl = 1u << lseq.back(); lseq.pop_back(); break; }
+                    const unsigned vl = nd.lflags(sv, v.f);
+                    if (vl == 0) { lfl = 0; sum += nd.count(sv); visited[sv] = 1; break; }
+                    else if (flag_count(vl) > 1) { lfl = 1u << lseq.back(); lseq.pop_back(); break; }
+                    lfl = vl;
+                    lseq.push_back((unsigned char)flag2base(vl));
+                    sum += nd.count(sv);
+                    visited[sv] = 1;
+                    Ori nx;
+                    nd.left_of(sv, v.f, nx.i, nx.f);
+                    v = nx;
+                }
+            }
+            if (lfl != 0) stack.push_back(lstop);
+            if (rfl != 0) stack.push_back(rstop);
+            Straight st;
+            st.length = lseq.size() + rseq.size() + 1;
+            st.seq.assign((st.length + k + 31) / 32, 0);
+            const u64 rn = rseq.size();
+            for (u64 j = 0; j < rn; ++j) st.set(rn - 1 - j, rseq[j]);
+            for (unsigned j = 0; j < k; ++j) st.set(rn + j, start.get(j));
+            for (u64 j = 0; j < lseq.size(); ++j) st.set(rn + k + j, lseq[j]);
+            st.coverage = (u16)(static_cast<double>(sum) / static_cast<double>(st.length) + 0.5);
+            st.out = (uint8_t)((lfl << 4) | rfl);
+            gr.insert_straight(st);
+        }
+    };
+    u64 pn = 0, pc = 0;
+    while (true) {
+        while (pn < nn && nd.chain[pn] < CHAIN_COMPLEX) ++pn;             // chain ends are reached through their chain's root
+        while (pc < nc && chain_done[by_root[pc]]) ++pc;
+        const bool have_n = pn < nn, have_c = pc < nc;
+        if (!have_n && !have_c) break;
+        const u64 in_ = have_n ? nd.idx[pn] : ~0ull, ic = have_c ? (u64)(cs.root[by_root[pc]] >> 1) : ~0ull;
+        stack.clear();
+        if (in_ < ic) {
+            if (!visited[pn]) { stack.push_back({(u64)nd.idx[pn], 0u}); run_stack(); }
+            ++pn;
+        } else {
+            const uint32_t c = by_root[pc];
+            take_chain(c, (cs.root[c] & 1u) == 0);                         // root k-mer in its canonical orientation (graph.h:334)
+            run_stack();
+            ++pc;
+        }
+    }
+}
+
+} // namespace pbh
