@@ -167,7 +167,9 @@ unsigned long long pbo_extend_kmer(double min_log_p_join, double avg_cov, double
 // Builds the retained set with the oracle's counter, computes the adjacency arrays the device would deliver
 // (pb_graph_adjacency's contract, include/pbgpu.h) with plain CPU probes, runs the PRODUCT's DFS replay
 // (platanus_b_amd/host/device_graph.hpp) and the oracle's k-mer-level DFS on the same set, and compares the two node
-// tables in container iteration order.  Returns 0 when identical, a positive code for the first difference.
+// tables in container iteration order.  Both product replays are checked: the k-mer-level one on the adjacency arrays
+// (codes 1-7) and the node-level one on the compact hand-over of pb_graph_chains / pb_graph_nodes, which is restated here
+// with plain loops (codes 11-17).  Returns 0 when identical, a positive code for the first difference.
 #include "graph.hpp"
 #include "../../platanus_b_amd/host/device_graph.hpp"
 
@@ -223,18 +225,120 @@ int replay_check(const ReadSet &rs, unsigned k, u64 min_occ)
     got.set_k(k);
     make_initial_from_device(got, in);
 
-    if (got.left.size() != ref.left.size()) return 1;
-    if (got.junctions.size() != ref.junctions.size()) return 2;
-    auto a = got.left.begin();
-    for (auto b = ref.left.begin(); b != ref.left.end(); ++a, ++b) {
-        if (!(a->first == b->first)) return 3;
-        if (a->second.length != b->second.length || a->second.coverage != b->second.coverage || a->second.out != b->second.out) return 4;
-        if (a->second.seq != b->second.seq) return 5;
+    // ---- the compact hand-over (pb_graph_chains + pb_graph_nodes contract, include/pbgpu.h) restated with plain loops, and the
+    //      product's node-level replay on it
+    Graph<W> got2;
+    got2.set_k(k);
+    {
+        auto is_junction = [&](u64 i) { return flag_count(adj[i] >> 4) > 1 || flag_count(adj[i] & 15u) > 1; };
+        const u64 NONE = ~0ull;
+        std::vector<u64> nxt(2 * n, NONE);
+        for (u64 s = 0; s < 2 * n; ++s) {
+            const u64 i = s >> 1;
+            const unsigned d = (unsigned)(s & 1);
+            if (is_junction(i)) continue;
+            const uint32_t v = nbr[2 * i + d];
+            if (v == 0xFFFFFFFFu) continue;
+            const u64 j = v >> 1;
+            if (!is_junction(j)) nxt[s] = 2 * j + (d ^ (v & 1u));
+        }
+        // terminal state and distance of every state (NONE: on a cycle)
+        auto walk = [&](u64 s, u64 &dist) -> u64 {
+            dist = 0;
+            u64 cur = s;
+            while (nxt[cur] != NONE) { cur = nxt[cur]; ++dist; if (dist > 2 * n) return NONE; }
+            return cur;
+        };
+        std::vector<uint32_t> chain_of(n, CHAIN_JUNCTION), pos_a(n, 0);
+        std::vector<uint8_t> orient(n, 0);
+        std::vector<u64> term_a(n, NONE);
+        for (u64 i = 0; i < n; ++i) {
+            if (is_junction(i)) continue;
+            u64 d0, d1;
+            const u64 t0 = walk(2 * i, d0), t1 = walk(2 * i + 1, d1);
+            if (t0 == NONE || t1 == NONE || t0 == t1) { chain_of[i] = CHAIN_COMPLEX; continue; }
+            const bool a_is_0 = t0 < t1;
+            term_a[i] = a_is_0 ? t0 : t1;
+            pos_a[i] = (uint32_t)(a_is_0 ? d0 : d1);
+            orient[i] = a_is_0 ? 1 : 0;
+            chain_of[i] = 0;
+        }
+        // dense chain ids in an arbitrary order (descending index of the A end, to differ from any natural order)
+        ChainRecords cr;
+        std::vector<long> id_of_a(n, -1);
+        for (u64 ii = n; ii-- > 0;) {
+            if (chain_of[ii] >= CHAIN_COMPLEX || pos_a[ii] != 0) continue;
+            id_of_a[ii] = (long)cr.len.size();
+            u64 db;
+            const u64 sb = 2 * ii + (orient[ii] ? 1u : 0u);
+            const u64 tb = walk(sb, db);
+            cr.len.push_back((uint32_t)(db + 1));
+            cr.end_a.push_back((uint32_t)((ii << 1) | orient[ii]));
+            cr.end_b.push_back((uint32_t)(((tb >> 1) << 1) | (tb & 1u)));
+            cr.sum.push_back(0);
+            cr.root.push_back(0xFFFFFFFFu);
+            cr.seq_woff.push_back(0);
+        }
+        const u64 nc = cr.len.size();
+        u64 words = 0;
+        for (u64 c2 = 0; c2 < nc; ++c2) { cr.seq_woff[c2] = words; words += ((u64)cr.len[c2] + k - 1 + 31) / 32; }
+        cr.seq.assign(words, 0);
+        for (u64 i = 0; i < n; ++i) {
+            if (chain_of[i] >= CHAIN_COMPLEX) continue;
+            const uint32_t cid = (uint32_t)id_of_a[term_a[i] >> 1];
+            chain_of[i] = cid;
+            cr.sum[cid] += counts[i];
+            cr.root[cid] = std::min(cr.root[cid], (uint32_t)((i << 1) | orient[i]));
+            Key<W> key = kv[i].first;
+            if (orient[i]) key = revcomp(key, k);
+            const u64 ls = (u64)cr.len[cid] + k - 1;
+            u64 *dst = cr.seq.data() + cr.seq_woff[cid];
+            auto put = [&](u64 p, unsigned code) { dst[p >> 5] |= (u64)code << ((p & 31) * 2); };
+            if (pos_a[i] == 0) for (unsigned b = 0; b < k; ++b) put(ls - 1 - b, key.get(k - 1 - b));
+            else put(ls - 1 - (k - 1 + pos_a[i]), key.get(0));
+        }
+        NodeSet<W> nd;
+        nd.k = k;
+        std::vector<uint8_t> mark(n, 0);
+        for (u64 c2 = 0; c2 < nc; ++c2) { mark[cr.end_a[c2] >> 1] = 1; mark[cr.end_b[c2] >> 1] = 1; }
+        for (u64 ii = n; ii-- > 0;) {                              // unsorted on purpose: the replay sorts
+            if (!(chain_of[ii] >= CHAIN_COMPLEX || mark[ii])) continue;
+            nd.idx.push_back((uint32_t)ii);
+            nd.meta.push_back((uint32_t)adj[ii] | ((uint32_t)(chain_of[ii] < CHAIN_COMPLEX ? orient[ii] : 0) << 8) | ((uint32_t)counts[ii] << 16));
+            nd.chain.push_back(chain_of[ii]);
+            nd.nbr.push_back(nbr[2 * ii]);
+            nd.nbr.push_back(nbr[2 * ii + 1]);
+            for (int w = 0; w < W; ++w) nd.keys.push_back(kv[ii].first.w[w]);
+            for (unsigned b = 0; b < 8; ++b) {
+                uint32_t e = 0xFFFFFFFFu;
+                if (chain_of[ii] == CHAIN_JUNCTION) {
+                    const Key<W> x = b < 4 ? tmp.succ(kv[ii].first, b) : tmp.pred(kv[ii].first, b - 4);
+                    const Key<W> r = revcomp(x, k);
+                    const bool flip = r < x;
+                    const long j = find_idx(flip ? r : x);
+                    if (j >= 0) e = ((uint32_t)j << 1) | (flip ? 1u : 0u);
+                }
+                nd.nb8.push_back(e);
+            }
+        }
+        make_initial_from_nodes(got2, nd, cr);
     }
-    auto ja = got.junctions.begin();
-    for (auto jb = ref.junctions.begin(); jb != ref.junctions.end(); ++ja, ++jb) {
-        if (!(ja->first == jb->first)) return 6;
-        if (ja->second.coverage != jb->second.coverage || ja->second.out != jb->second.out) return 7;
+    for (int which = 0; which < 2; ++which) {
+        Graph<W> &gx = which == 0 ? got : got2;
+        const int base = which * 10;
+        if (gx.left.size() != ref.left.size()) return base + 1;
+        if (gx.junctions.size() != ref.junctions.size()) return base + 2;
+        auto a = gx.left.begin();
+        for (auto b = ref.left.begin(); b != ref.left.end(); ++a, ++b) {
+            if (!(a->first == b->first)) return base + 3;
+            if (a->second.length != b->second.length || a->second.coverage != b->second.coverage || a->second.out != b->second.out) return base + 4;
+            if (a->second.seq != b->second.seq) return base + 5;
+        }
+        auto ja = gx.junctions.begin();
+        for (auto jb = ref.junctions.begin(); jb != ref.junctions.end(); ++ja, ++jb) {
+            if (!(ja->first == jb->first)) return base + 6;
+            if (ja->second.coverage != jb->second.coverage || ja->second.out != jb->second.out) return base + 7;
+        }
     }
     return 0;
 }
