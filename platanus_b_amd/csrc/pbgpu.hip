@@ -332,7 +332,7 @@ static int table_to_arrays(pb_ctx *ctx, u64 upper_bound, bool append)
     TableView<W> tv{(u64 *)ctx->table.p, ctx->table_cap - 1};
     HIPCHK(hipMemsetAsync(ctx->d_scalars.p, 0, 16 * 8, ctx->stream));
     StageTimer tm(ctx, "compact");
-    table_to_arrays_kernel<W><<<grid_for(ctx->table_cap, 256, 256 * 8), 256, 0, ctx->stream>>>(
+    table_to_arrays_kernel<W><<<grid_for(ctx->table_cap, 256 * T2A_SPT, 256 * 8), 256, 0, ctx->stream>>>(
         tv, (u64 *)ctx->dist_keys.p + base * W, (u32 *)ctx->dist_counts.p + base, cap_out - base, (u64 *)ctx->d_scalars.p);
     HIPCHK(hipGetLastError());
     if ((rc = tm.stop()) != PB_OK) return rc;
