@@ -95,6 +95,10 @@ int pb_export_copy(pb_ctx *ctx, void *dev_keys, void *dev_counts);
 int pb_merge_begin(pb_ctx *ctx, unsigned k, uint64_t expected_records);
 int pb_merge_add(pb_ctx *ctx, const void *dev_keys, const void *dev_counts, uint64_t n);
 int pb_merge_end(pb_ctx *ctx, uint64_t *occ_hist, uint64_t *max_occ, uint64_t *n_distinct);
+/* pb_merge_begin + one pb_merge_add + pb_merge_end in one call; for k <= 32 and >= 1 M records the records are merged through
+ * the counting pass's partition + LDS tables instead of a global table (same result, no random device-scope atomics). */
+int pb_merge_records(pb_ctx *ctx, unsigned k, const void *dev_keys, const void *dev_counts, uint64_t n, uint64_t *occ_hist,
+                     uint64_t *max_occ, uint64_t *n_distinct);
 
 /* ---- graph stage: device part of BruijnGraph::makeInitialBruijnGraph (graph.h:289-579) ------------------------ */
 /* On the retained, sorted set of the last pb_retain (n keys).  For retained k-mer i in its canonical orientation:

@@ -66,6 +66,7 @@ def load_library() -> C.CDLL:
     lib.pb_merge_begin.argtypes = [vp, C.c_uint, C.c_uint64]
     lib.pb_merge_add.argtypes = [vp, vp, vp, C.c_uint64]
     lib.pb_merge_end.argtypes = [vp, vp, u64p, u64p]
+    lib.pb_merge_records.argtypes = [vp, C.c_uint, vp, vp, C.c_uint64, vp, u64p, u64p]
     lib.pb_kmer_occ_layout.argtypes = [vp, C.c_uint64, C.c_uint, u64p, u64p]
     lib.pb_kmer_occ_fetch.argtypes = [vp, vp, vp, vp]
     _lib = lib

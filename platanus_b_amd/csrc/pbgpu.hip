@@ -56,6 +56,7 @@ struct pb_ctx {
     DevBuf dist_keys, dist_counts;      // u64[n*W], u32[n]
     int count_path = 0;                 // 1 = direct (v1), 2 = partitioned (v2)
     DevBuf part_bucket1, part_bucket2, part_meta, part_spill;
+    u64 exp_cur[64] = {0};           // start of every owner's segment in the export (pb_export_begin -> pb_export_copy)
     u64 sk_records = 0;            // super-k-mer records of the last counting pass (0 = other path)
     u64 sk_flagged = 0, sk_spilled = 0, sk_extra_for = 0;
     unsigned sk_bits = 0, sk_extra_bits = 0;       // bucket bits used; extra bits that an earlier pass over the same stream needed
@@ -663,24 +664,23 @@ int pb_export_begin(pb_ctx *ctx, int n_parts, uint64_t *part_counts)
     for (int i = 0; i < n_parts; ++i) { cur[i] = total; total += h[i]; part_counts[i] = h[i]; }
     ctx->exp_total = total;
     ctx->exp_parts = (unsigned)n_parts;
-    if ((rc = ensure(ctx, ctx->exp_keys, std::max<u64>(total, 1) * W * 8)) != PB_OK) return rc;
-    if ((rc = ensure(ctx, ctx->exp_counts, std::max<u64>(total, 1) * 4)) != PB_OK) return rc;
-    u64 *cursors = (u64 *)pc.p + PB_MAX_PARTS;
-    HIPCHK(hipMemcpyAsync(cursors, cur, n_parts * 8, hipMemcpyHostToDevice, ctx->stream));
-    if (nd)
-        part_scatter_kernel<<<grid_for(nd, 256, 256 * 8), 256, 0, ctx->stream>>>((const u64 *)ctx->dist_keys.p, (const u32 *)ctx->dist_counts.p, nd, W,
-                                                                                 (unsigned)n_parts, cursors, (u64 *)ctx->exp_keys.p, (u32 *)ctx->exp_counts.p);
+    for (int i = 0; i < n_parts; ++i) ctx->exp_cur[i] = cur[i];
     HIPCHK(hipGetLastError());
     return tm.stop();
 }
 
+// the records are scattered straight into the caller's buffers (no staging copy)
 int pb_export_copy(pb_ctx *ctx, void *dev_keys, void *dev_counts)
 {
     if (!ctx || ctx->exp_parts == 0) return PB_EINVAL;
     (void)hipSetDevice(ctx->dev);
-    if (ctx->exp_total) {
-        HIPCHK(hipMemcpyAsync(dev_keys, ctx->exp_keys.p, ctx->exp_total * ctx->W * 8, hipMemcpyDeviceToDevice, ctx->stream));
-        HIPCHK(hipMemcpyAsync(dev_counts, ctx->exp_counts.p, ctx->exp_total * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    const u64 nd = ctx->n_distinct;
+    if (ctx->exp_total && nd) {
+        u64 *cursors = (u64 *)ctx->scratch[0].p + PB_MAX_PARTS;
+        HIPCHK(hipMemcpyAsync(cursors, ctx->exp_cur, ctx->exp_parts * 8, hipMemcpyHostToDevice, ctx->stream));
+        part_scatter_kernel<<<grid_for(nd, 256 * PSC_RPT, 256 * 8), 256, 0, ctx->stream>>>((const u64 *)ctx->dist_keys.p, (const u32 *)ctx->dist_counts.p, nd, ctx->W,
+                                                                                         ctx->exp_parts, cursors, (u64 *)dev_keys, (u32 *)dev_counts);
+        HIPCHK(hipGetLastError());
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return PB_OK;
@@ -723,6 +723,84 @@ static int merge_begin_impl(pb_ctx *ctx, u64 cap)
 #define PB_DISPATCH_W(ctx, fn, ...)                                   \
     ((ctx)->W == 1 ? fn<1>(__VA_ARGS__) : (ctx)->W == 2 ? fn<2>(__VA_ARGS__) : (ctx)->W == 3 ? fn<3>(__VA_ARGS__) \
      : (ctx)->W == 4 ? fn<4>(__VA_ARGS__) : fn<5>(__VA_ARGS__))
+
+// owner-side merge through the partition + LDS machinery (k <= 32); *done = false: the caller uses the table path
+static int merge_records_lds(pb_ctx *ctx, const void *dev_keys, const void *dev_counts, u64 n, bool *done)
+{
+    int rc;
+    *done = false;
+    if (n < (1ull << 20)) return PB_OK;
+    SkParams p;
+    p.abl = 0;
+    p.k = ctx->k; p.m = 0; p.w = 0; p.L = 0;
+    unsigned B = 8;
+    while (((u64)1536 << B) < n && B < 20) ++B;            // hash-uniform buckets: mean <= 1536 distinct keys, the table takes 3840
+    if (((u64)1536 << B) < n) return PB_OK;
+    p.B = B;
+    p.l1 = B / 2;
+    p.l2 = B - p.l1;
+    const u64 nb1 = (1ull << p.l1) * PB_XCD, nb2 = 1ull << B;
+    p.cap1 = n / nb1 * 3 / 2 + 4096;
+    p.cap2 = (u32)(n / nb2 * 2 + 256);
+    if ((rc = ensure(ctx, ctx->part_bucket1, nb1 * p.cap1 * sizeof(SkRec))) != PB_OK) return rc;
+    if ((rc = ensure(ctx, ctx->part_bucket2, nb2 * (u64)p.cap2 * sizeof(SkRec))) != PB_OK) return rc;
+    if ((rc = ensure(ctx, ctx->part_meta, (nb1 + 2 * nb2) * 4)) != PB_OK) return rc;
+    p.spill_cap = 1ull << 16;
+    if ((rc = ensure(ctx, ctx->part_spill, p.spill_cap * sizeof(SkRec))) != PB_OK) return rc;
+    p.spill = (SkRec *)ctx->part_spill.p;
+    p.bucket1 = (SkRec *)ctx->part_bucket1.p;
+    p.bucket2 = (SkRec *)ctx->part_bucket2.p;
+    p.cursor1 = (u32 *)ctx->part_meta.p;
+    p.cursor2 = p.cursor1 + nb1;
+    p.flag2 = p.cursor2 + nb2;
+    p.fallback = TableView<1>{nullptr, 0};
+    p.scalars = (u64 *)ctx->d_scalars.p;
+    if ((rc = ensure(ctx, ctx->dist_keys, n * 8)) != PB_OK) return rc;
+    if ((rc = ensure(ctx, ctx->dist_counts, n * 4)) != PB_OK) return rc;
+    HIPCHK(hipMemsetAsync(ctx->d_scalars.p, 0, 16 * 8, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->part_meta.p, 0, (nb1 + 2 * nb2) * 4, ctx->stream));
+    StageTimer tm(ctx, "merge");
+    mg_part1_kernel<<<grid_for((n + SK2_RCAP - 1) / SK2_RCAP, 1, 256 * 8), SK_THREADS, 0, ctx->stream>>>((const u64 *)dev_keys, (const u32 *)dev_counts, n, p);
+    const u64 exp_tiles = n / nb1 / SK2_RCAP + 1;
+    sk_part2_kernel<<<dim3((unsigned)std::min<u64>(std::max<u64>(exp_tiles / 4, 1), 64), (unsigned)nb1), SK_THREADS, 0, ctx->stream>>>(p);
+    mg_bucket_kernel<<<grid_for(nb2, 1, 256 * 16), SK_ROLL_THREADS, 0, ctx->stream>>>(p, (u64 *)ctx->dist_keys.p, (u32 *)ctx->dist_counts.p, n);
+    HIPCHK(hipGetLastError());
+    u64 sc[9];
+    HIPCHK(hipMemcpyAsync(sc, ctx->d_scalars.p, 72, hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = tm.stop()) != PB_OK) return rc;
+    if (sc[1] || sc[7] || sc[8]) return PB_OK;              // a region or a table overflowed (one key with a huge share): the table path takes it
+    ctx->n_distinct = sc[4];
+    ctx->n_retained = 0;
+    *done = true;
+    return PB_OK;
+}
+
+extern "C" {
+
+int pb_merge_records(pb_ctx *ctx, unsigned k, const void *dev_keys, const void *dev_counts, uint64_t n, uint64_t *occ_hist, uint64_t *max_occ,
+                     uint64_t *n_distinct)
+{
+    if (!ctx || k < 1 || k > PB_MAX_K || (n && (!dev_keys || !dev_counts))) return PB_EINVAL;
+    (void)hipSetDevice(ctx->dev);
+    int rc;
+    ctx->k = k;
+    ctx->W = (int)((k + 31) / 32);
+    if ((rc = ensure(ctx, ctx->d_scalars, 16 * 8)) != PB_OK) return rc;
+    bool done = false;
+    if (ctx->W == 1 && !getenv("PB_MERGE_TABLE")) {
+        if ((rc = merge_records_lds(ctx, dev_keys, dev_counts, n, &done)) != PB_OK) return rc;
+    }
+    if (done) {
+        if ((rc = finish_count(ctx, occ_hist, max_occ)) != PB_OK) return rc;
+        if (n_distinct) *n_distinct = ctx->n_distinct;
+        return PB_OK;
+    }
+    if ((rc = pb_merge_begin(ctx, k, std::max<u64>(n, 1))) != PB_OK) return rc;
+    if ((rc = pb_merge_add(ctx, dev_keys, dev_counts, n)) != PB_OK) return rc;
+    return pb_merge_end(ctx, occ_hist, max_occ, n_distinct);
+}
+
+} // extern "C"
 
 extern "C" {
 

@@ -56,11 +56,9 @@ def exchange_and_merge(g, dist, world: int, rank: int):
     rk, rcnt, recv = exchange_records(dist, torch, keys[:n * W], counts[:n], send, W)
     torch.cuda.synchronize()                 # the library runs on its own stream
     total = sum(recv)
-    g._chk(lib.pb_merge_begin(h, g.k, max(total, 1)))
-    g._chk(lib.pb_merge_add(h, C.c_void_p(rk.data_ptr()), C.c_void_p(rcnt.data_ptr()), total))
     hist = np.zeros(PB_OCC_BINS, dtype=np.uint64)
     mx, nd = C.c_uint64(), C.c_uint64()
-    g._chk(lib.pb_merge_end(h, hist.ctypes.data, C.byref(mx), C.byref(nd)))
+    g._chk(lib.pb_merge_records(h, g.k, C.c_void_p(rk.data_ptr()), C.c_void_p(rcnt.data_ptr()), total, hist.ctypes.data, C.byref(mx), C.byref(nd)))
     th = torch.from_numpy(hist.astype(np.int64)).to(dev)
     dist.all_reduce(th)
     ghist = th.cpu().numpy().astype(np.uint64)

@@ -340,3 +340,48 @@ def test_superkmer_low_coverage_mostly_distinct(gpu, oracle_built, monkeypatch):
     monkeypatch.setenv("PB_COUNT_PATH", "superk")
     r1, r2 = synth.make_reads(300_000, 2, seed=191, err=0.02)
     _superk_case(gpu, oracle_built, np.concatenate([r1, r2]), 31, cutoffs=(1,))
+
+
+def test_merge_records_through_lds_tables(gpu, oracle_built, monkeypatch):
+    """pb_merge_records on > 1 M records takes the partition + LDS-table path (stage "merge" of the counting machinery); the
+    result must equal both the oracle and the global-table path (PB_MERGE_TABLE=1).  Input: every distinct k-mer of a 2 %-error
+    read set split into two records whose counts add up, plus a heavy hitter that arrives as 3000 records."""
+    import ctypes as C
+    import torch
+    from platanus_b_amd import synth
+    k = 31
+    r1, r2 = synth.make_reads(400_000, 16, seed=23, err=0.02)
+    codes = np.concatenate([r1, r2])
+    n, L = codes.shape
+    off = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
+    oc = _oracle(codes, off, k, oracle_built)
+    ok, ocn = oc.retain(1)
+    ohist, omax = oc.occ_hist()
+    g = gpu(0)
+    g.reads_append_matrix(codes)
+    g.make_kmer_read_distribution(k)
+    keys, counts = g.fetch_all()
+    keys = keys.reshape(-1)
+    assert len(keys) == len(ok) and len(keys) > 1_000_000
+    rng = np.random.default_rng(5)
+    first = (counts.astype(np.int64) * rng.random(len(counts))).astype(np.int64)
+    rk = np.concatenate([keys, keys])
+    rc = np.concatenate([first, counts.astype(np.int64) - first])          # zero counts are legal records: ignored
+    hot = int(np.argmax(counts))
+    rk = np.concatenate([rk, np.full(3000, keys[hot], dtype=np.uint64)])
+    rc = np.concatenate([rc, np.full(3000, 20, dtype=np.int64)])
+    perm = rng.permutation(len(rk))
+    tk = torch.from_numpy(rk[perm].view(np.int64)).cuda()
+    tc = torch.from_numpy(rc[perm].astype(np.int32)).cuda()
+    expect = np.minimum(ocn.astype(np.int64) + np.where(ok.reshape(-1) == keys[hot], 60000, 0), 65534).astype(np.uint16)
+    for table_path in (False, True):
+        if table_path:
+            monkeypatch.setenv("PB_MERGE_TABLE", "1")
+        hist = np.zeros(65535, dtype=np.uint64)
+        mx, nd = C.c_uint64(), C.c_uint64()
+        torch.cuda.synchronize()
+        g._chk(g.lib.pb_merge_records(g.h, k, C.c_void_p(tk.data_ptr()), C.c_void_p(tc.data_ptr()), len(rk), hist.ctypes.data, C.byref(mx), C.byref(nd)))
+        assert nd.value == len(ok), table_path
+        g.retain(1)
+        gk, gc = g.fetch_retained()
+        assert np.array_equal(gk.reshape(-1), ok.reshape(-1)) and np.array_equal(gc, expect), table_path
