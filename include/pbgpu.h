@@ -59,6 +59,8 @@ int         pb_device_info(const pb_ctx *ctx, char *name, size_t name_cap, int *
  * reads are packed to 2 bits/base plus a 1-bit unknown-base mask (kernel K1).  Append order = the order of
  * the reference's temp file 0 at -t 1 (file 1's reads, then file 2's, ...). */
 int pb_reads_append(pb_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads, int ascii);
+/* optional: announce how much pb_reads_append calls will bring in total, so that the packed stream is allocated once */
+int pb_reads_reserve(pb_ctx *ctx, uint64_t n_bases, uint64_t n_reads);
 int pb_reads_clear(pb_ctx *ctx);
 int pb_reads_info(const pb_ctx *ctx, uint64_t *n_reads, uint64_t *n_bases);
 /* lengthDistribution (counter.h:328-333): hist[len] for len < hist_n; *sum_len, *n_reads for the mean */

@@ -17,6 +17,7 @@
 #include <map>
 #include <string>
 #include <vector>
+#include <thread>
 
 // ------------------------------------------------------------------------------------------------------
 // context
@@ -56,6 +57,12 @@ struct pb_ctx {
     DevBuf dist_keys, dist_counts;      // u64[n*W], u32[n]
     int count_path = 0;                 // 1 = direct (v1), 2 = partitioned (v2)
     DevBuf part_bucket1, part_bucket2, part_meta, part_spill;
+    void *bounce[2] = {nullptr, nullptr};   // pinned staging buffers of upload_bases
+    hipEvent_t bounce_ev[2];
+    bool bounce_used[2] = {false, false};
+    std::vector<u64> rel_keep[2];
+    int rel_next = 0;
+    int bounce_next = 0;
     u64 exp_cur[64] = {0};           // start of every owner's segment in the export (pb_export_begin -> pb_export_copy)
     u64 sk_records = 0;            // super-k-mer records of the last counting pass (0 = other path)
     u64 sk_flagged = 0, sk_spilled = 0, sk_extra_for = 0;
@@ -200,6 +207,7 @@ void pb_destroy(pb_ctx *ctx)
     release(ctx->chain_work); release(ctx->chain_rec); release(ctx->chain_seq);
     release(ctx->layout_work); release(ctx->layout_slots); release(ctx->layout_out); release(ctx->scan_sums); release(ctx->slot_blk);
     for (auto &s : ctx->scratch) release(s);
+    for (int b = 0; b < 2; ++b) if (ctx->bounce[b]) { (void)hipHostFree(ctx->bounce[b]); (void)hipEventDestroy(ctx->bounce_ev[b]); }
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
     (void)hipStreamDestroy(ctx->stream);
@@ -246,12 +254,64 @@ int pb_reads_length_hist(pb_ctx *ctx, uint64_t *hist, uint64_t hist_n)
 }
 
 
+// Host -> device copy of a large pageable buffer through two pinned bounce buffers: several host threads fill one while the DMA
+// engine drains the other (a plain hipMemcpy from pageable memory stages through one thread: ~5 GB/s measured).
+static int upload_bases(pb_ctx *ctx, unsigned char *dst, const uint8_t *src, u64 n)
+{
+    const u64 CH = 8ull << 20;
+    if (n < (4ull << 20)) {
+        HIPCHK(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, ctx->stream));
+        return PB_OK;
+    }
+    if (!ctx->bounce[0]) {
+        for (int b = 0; b < 2; ++b) {
+            HIPCHK(hipHostMalloc(&ctx->bounce[b], CH, hipHostMallocDefault));
+            HIPCHK(hipEventCreateWithFlags(&ctx->bounce_ev[b], hipEventDisableTiming));
+        }
+    }
+    const unsigned nt = std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+    for (u64 o = 0; o < n; o += CH) {
+        const int b = ctx->bounce_next;
+        ctx->bounce_next ^= 1;
+        const u64 len = std::min(CH, n - o);
+        if (ctx->bounce_used[b]) HIPCHK(hipEventSynchronize(ctx->bounce_ev[b]));      // the copy that last used this buffer has left it
+        ctx->bounce_used[b] = true;
+        std::vector<std::thread> th;
+        const u64 part = (len + nt - 1) / nt;
+        for (unsigned t = 0; t < nt; ++t) {
+            const u64 lo = (u64)t * part, hi = std::min(len, lo + part);
+            if (lo < hi) th.emplace_back([=]() { memcpy((char *)ctx->bounce[b] + lo, src + o + lo, hi - lo); });
+        }
+        for (auto &t : th) t.join();
+        HIPCHK(hipMemcpyAsync(dst + o, ctx->bounce[b], len, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipEventRecord(ctx->bounce_ev[b], ctx->stream));
+    }
+    return PB_OK;
+}
+
+int pb_reads_reserve(pb_ctx *ctx, uint64_t n_bases, uint64_t n_reads)
+{
+    if (!ctx) return PB_EINVAL;
+    (void)hipSetDevice(ctx->dev);
+    const u64 new_len = ctx->stream_len + n_bases + n_reads;
+    const u64 words64 = (new_len + 63) / 64 + PB_STREAM_PAD_WORDS64;
+    int rc;
+    if ((rc = ensure(ctx, ctx->packed, words64 * 16, true)) != PB_OK) return rc;
+    if ((rc = ensure(ctx, ctx->nmask, words64 * 8, true)) != PB_OK) return rc;
+    ctx->read_start.reserve(ctx->read_start.size() + n_reads + 1);
+    return PB_OK;
+}
+
 int pb_reads_append(pb_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads, int ascii)
 {
     if (!ctx || !offsets || (n_reads && !bases && offsets[n_reads] > 0)) return PB_EINVAL;
     if (n_reads == 0) return PB_OK;
     (void)hipSetDevice(ctx->dev);
     const u64 n_new_bases = offsets[n_reads] - offsets[0];
+    static const bool trace = getenv("PB_TRACE_APPEND") != nullptr;
+    auto now = []() { return std::chrono::steady_clock::now(); };
+    auto t0 = now();
+    auto lap = [&](const char *what) { if (trace) { auto t1 = now(); fprintf(stderr, "  append %-10s %.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count()); t0 = t1; } };
     for (u64 r = 0; r < n_reads; ++r) {
         const u64 len = offsets[r + 1] - offsets[r];
         if (len >= 500000) { ctx->err = "read of 500000 bases or more (common.cpp:28)"; return PB_ERANGE; }
@@ -266,22 +326,31 @@ int pb_reads_append(pb_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, 
     if ((rc = ensure(ctx, ctx->packed, words64 * 16, true)) != PB_OK) return rc;
     if ((rc = ensure(ctx, ctx->nmask, words64 * 8, true)) != PB_OK) return rc;
     (void)fresh;
+    lap("hist+ens");
     // staging copy of the host buffers
     DevBuf &d_bases = ctx->scratch[0], &d_off = ctx->scratch[1];
     if ((rc = ensure(ctx, d_bases, n_new_bases + 16)) != PB_OK) return rc;
     if ((rc = ensure(ctx, d_off, (n_reads + 1) * 8)) != PB_OK) return rc;
-    std::vector<u64> rel(n_reads + 1);
+    // offsets relative to this batch; the vector stays alive in the context until two calls later (the copy below may read it
+    // asynchronously; a later bounce-buffer wait in upload_bases, or the stream synchronisation for small batches, covers it)
+    std::vector<u64> &rel = ctx->rel_keep[ctx->rel_next];
+    ctx->rel_next ^= 1;
+    rel.resize(n_reads + 1);
     for (u64 r = 0; r <= n_reads; ++r) rel[r] = offsets[r] - offsets[0];
-    HIPCHK(hipMemcpyAsync(d_bases.p, bases + offsets[0], n_new_bases, hipMemcpyHostToDevice, ctx->stream));
+    lap("rel");
     HIPCHK(hipMemcpyAsync(d_off.p, rel.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    StageTimer tm(ctx, "pack");
+    if ((rc = upload_bases(ctx, (unsigned char *)d_bases.p, bases + offsets[0], n_new_bases)) != PB_OK) return rc;
+    if (n_new_bases < (4ull << 20)) HIPCHK(hipStreamSynchronize(ctx->stream));
+    lap("upload");
     const u64 first64 = old_len / 64;
     const u64 n64 = words64 - first64;          // includes the all-unknown padding words
     pack_reads_kernel<<<(unsigned)((n64 + 255) / 256), 256, 0, ctx->stream>>>(
         (const unsigned char *)d_bases.p, (const u64 *)d_off.p, n_reads, old_len, new_len, (u64 *)ctx->packed.p,
         (u64 *)ctx->nmask.p, first64, n64, ascii);
     HIPCHK(hipGetLastError());
-    if ((rc = tm.stop()) != PB_OK) return rc;
+    // no synchronisation here: the next call's host-side staging overlaps this call's DMA and pack kernel (both are ordered on
+    // the context's stream; every consumer of the stream runs on the same stream)
+    lap("pack");
     if (!ctx->read_start.empty()) ctx->read_start.pop_back();
     for (u64 r = 0; r < n_reads; ++r) ctx->read_start.push_back(old_len + rel[r] + r);
     ctx->read_start.push_back(new_len);
@@ -290,6 +359,7 @@ int pb_reads_append(pb_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, 
     ctx->stream_len = new_len;
     ctx->n_reads += n_reads;
     ctx->n_bases += n_new_bases;
+    lap("starts");
     return PB_OK;
 }
 

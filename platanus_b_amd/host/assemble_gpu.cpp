@@ -367,38 +367,23 @@ template <typename F> void dispatch_w(unsigned k, F &&f)
 }
 
 // FASTA/FASTQ reader with the reference's line rules (assemble.cpp:790-986); bases are handed over as ASCII, the device
-// applies Char2Bin (common.h:256).  The file is slurped once and split with memchr; sequence lines are appended straight
-// into `bases` (the reference's `read += oneLine` followed by the flush into the temp file).
-void read_file(const std::string &path, std::string &bases, std::vector<u64> &off)
+// applies Char2Bin (common.h:256).  Sequence lines are appended straight into `bases` (the reference's `read += oneLine`
+// followed by the flush into the temp file).
+//
+// A plain file is parsed out of the page cache by several threads.  The reference's line rules make every line that starts
+// with the record mark ('@' / '>') a restart point: there the sequential parser flushes the read collected so far if it is
+// not empty and forgets everything else.  So the file is cut at such lines, every piece is parsed independently (flushing a
+// pending read at its end only if it is not empty), and the pieces in file order give exactly the sequential result; only
+// the last piece ends with the reference's unconditional trailing flush.
+struct ParsedPiece {
+    std::string bases;
+    std::vector<u64> off{0};
+};
+
+void parse_piece(const char *p, const char *end, bool fastq, bool first_piece, bool last_piece, ParsedPiece &out)
 {
-    FILE *fp = nullptr;
-    bool piped = false;
-    const size_t L = path.size();
-    if (L > 3 && path.compare(L - 3, 3, ".gz") == 0) { fp = popen(("gzip -cd " + path).c_str(), "r"); piped = true; }
-    else if (L > 4 && path.compare(L - 4, 4, ".bz2") == 0) { fp = popen(("bzip2 -cd " + path).c_str(), "r"); piped = true; }
-    else fp = fopen(path.c_str(), "rb");
-    if (!fp) throw std::runtime_error("cannot open " + path);
-    std::string buf;
-    const char *data = nullptr;
-    size_t size = 0;
-    void *map = MAP_FAILED;
-    if (!piped) {                                 // plain file: parse straight out of the page cache
-        struct stat st;
-        if (fstat(fileno(fp), &st) == 0 && st.st_size > 0) {
-            map = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fileno(fp), 0);
-            if (map != MAP_FAILED) { data = (const char *)map; size = (size_t)st.st_size; madvise(map, size, MADV_SEQUENTIAL); }
-        }
-    }
-    if (map == MAP_FAILED) {
-        std::vector<char> chunk(16u << 20);
-        size_t got;
-        while ((got = fread(chunk.data(), 1, chunk.size(), fp)) > 0) buf.append(chunk.data(), got);
-        data = buf.data();
-        size = buf.size();
-    }
-    if (piped) pclose(fp); else fclose(fp);
-    struct Unmap { void *m; size_t n; ~Unmap() { if (m != MAP_FAILED) munmap(m, n); } } unmap{map, size};
-    const char *p = data, *end = p + size;
+    std::string &bases = out.bases;
+    std::vector<u64> &off = out.off;
     const char *ls = nullptr;
     size_t len = 0;
     auto next_line = [&]() -> bool {            // std::getline: a last line without '\n' counts, nothing after the final '\n'
@@ -409,16 +394,14 @@ void read_file(const std::string &path, std::string &bases, std::vector<u64> &of
         p = nl ? nl + 1 : end;
         return true;
     };
-    if (!next_line()) throw std::runtime_error("empty read file " + path);
-    const bool fastq = len > 0 && ls[0] == '@';
-    if (!fastq && !(len > 0 && ls[0] == '>')) throw std::runtime_error("Read file exception!!\nRead file is not FASTA/FASTQ format.");
-    bases.reserve(bases.size() + size / 2);
-    u64 read_start = bases.size();             // the current read = bases[read_start, bases.size())
+    bases.reserve((size_t)(end - p) / 2 + 64);
+    u64 read_start = 0;                         // the current read = bases[read_start, bases.size())
     auto flush = [&]() {
         if (bases.size() - read_start >= 500000) throw std::runtime_error("Read file exception!!\nread length is too long");   // common.h:465-467
         off.push_back(bases.size());
         read_start = bases.size();
     };
+    if (first_piece) next_line();               // the format line has been looked at by the caller; the reference consumes it the same way
     if (fastq) {
         bool flag = true;
         while (next_line()) {
@@ -436,7 +419,68 @@ void read_file(const std::string &path, std::string &bases, std::vector<u64> &of
             else if (bases.size() != read_start) flush();
         }
     }
-    flush();                                               // trailing read, written even when empty
+    if (last_piece || bases.size() != read_start) flush();     // the file's trailing read is written even when empty
+}
+
+void read_file(const std::string &path, std::vector<ParsedPiece> &pieces, unsigned max_threads)
+{
+    FILE *fp = nullptr;
+    bool piped = false;
+    const size_t L = path.size();
+    if (L > 3 && path.compare(L - 3, 3, ".gz") == 0) { fp = popen(("gzip -cd " + path).c_str(), "r"); piped = true; }
+    else if (L > 4 && path.compare(L - 4, 4, ".bz2") == 0) { fp = popen(("bzip2 -cd " + path).c_str(), "r"); piped = true; }
+    else fp = fopen(path.c_str(), "rb");
+    if (!fp) throw std::runtime_error("cannot open " + path);
+    std::string buf;
+    const char *data = nullptr;
+    size_t size = 0;
+    void *map = MAP_FAILED;
+    if (!piped) {                                 // plain file: parse straight out of the page cache
+        struct stat st;
+        if (fstat(fileno(fp), &st) == 0 && st.st_size > 0) {
+            map = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fileno(fp), 0);
+            if (map != MAP_FAILED) { data = (const char *)map; size = (size_t)st.st_size; madvise(map, size, MADV_WILLNEED); }
+        }
+    }
+    if (map == MAP_FAILED) {
+        std::vector<char> chunk(16u << 20);
+        size_t got;
+        while ((got = fread(chunk.data(), 1, chunk.size(), fp)) > 0) buf.append(chunk.data(), got);
+        data = buf.data();
+        size = buf.size();
+    }
+    if (piped) pclose(fp); else fclose(fp);
+    struct Unmap { void *m; size_t n; ~Unmap() { if (m != MAP_FAILED) munmap(m, n); } } unmap{map, size};
+    if (size == 0) throw std::runtime_error("empty read file " + path);
+    const bool fastq = data[0] == '@';
+    if (!fastq && data[0] != '>') throw std::runtime_error("Read file exception!!\nRead file is not FASTA/FASTQ format.");
+    // cut points: the first line at or after i * size / n that starts with the record mark
+    const char mark = fastq ? '@' : '>';
+    unsigned n = (unsigned)std::min<size_t>(std::max<unsigned>(max_threads, 1), size / (8u << 20) + 1);
+    std::vector<size_t> cut{0};
+    for (unsigned i = 1; i < n; ++i) {
+        size_t pos = size / n * i;
+        if (pos <= cut.back()) continue;
+        while (true) {                            // next line start
+            const char *nl = (const char *)memchr(data + pos, '\n', size - pos);
+            if (!nl) { pos = size; break; }
+            pos = (size_t)(nl - data) + 1;
+            if (pos >= size || data[pos] == mark) break;
+        }
+        if (pos < size && pos > cut.back()) cut.push_back(pos);
+    }
+    cut.push_back(size);
+    const size_t np = cut.size() - 1;
+    pieces.assign(np, ParsedPiece());
+    std::vector<std::string> err(np);
+    std::vector<std::thread> th;
+    for (size_t i = 0; i < np; ++i)
+        th.emplace_back([&, i]() {
+            try { parse_piece(data + cut[i], data + cut[i + 1], fastq, i == 0, i + 1 == np, pieces[i]); }
+            catch (const std::exception &e) { err[i] = e.what(); if (err[i].empty()) err[i] = "read error"; }
+        });
+    for (auto &t : th) t.join();
+    for (size_t i = 0; i < np; ++i) if (!err[i].empty()) throw std::runtime_error(err[i]);
 }
 
 } // namespace
@@ -457,33 +501,46 @@ int run_assemble_gpu(const GpuAssembleOptions &opt)
     // the input files are parsed concurrently (one host thread per file, at most 8 at a time) and handed to the device in
     // the order of the command line, which is the order of the reference's temp file 0 at -t 1
     const size_t nf = opt.files.size();
-    std::vector<std::string> fbases(nf);
-    std::vector<std::vector<u64>> foff(nf, std::vector<u64>{0});
+    std::vector<std::thread> reapers;
+    struct JoinAll { std::vector<std::thread> &v; ~JoinAll() { for (auto &t : v) if (t.joinable()) t.join(); } } join_reapers{reapers};
+    std::vector<std::vector<ParsedPiece>> fpieces(nf);
     std::vector<std::string> ferr(nf);
+    const unsigned hw = std::max(2u, std::thread::hardware_concurrency());
     for (size_t base = 0; base < nf; base += 8) {
         const size_t hi_f = std::min(nf, base + 8);
+        const unsigned per_file = std::max<unsigned>(1, std::min(16u, hw) / (unsigned)(hi_f - base));
         {
             Tick t("read + parse files (host threads)");
             std::vector<std::thread> th;
             for (size_t i = base; i < hi_f; ++i)
-                th.emplace_back([&, i]() { try { read_file(opt.files[i], fbases[i], foff[i]); } catch (const std::exception &e) { ferr[i] = e.what(); if (ferr[i].empty()) ferr[i] = "read error"; } });
+                th.emplace_back([&, i]() { try { read_file(opt.files[i], fpieces[i], per_file); } catch (const std::exception &e) { ferr[i] = e.what(); if (ferr[i].empty()) ferr[i] = "read error"; } });
             for (auto &t2 : th) t2.join();
+        }
+        {
+            Tick t("device allocation for the read stream");
+            u64 tb = 0, tr = 0;
+            for (size_t i = base; i < hi_f; ++i) for (const ParsedPiece &pc : fpieces[i]) { tb += pc.bases.size(); tr += pc.off.size() - 1; }
+            d.chk(pb_reads_reserve(d.ctx, tb, tr));
         }
         for (size_t i = base; i < hi_f; ++i) {
             if (!ferr[i].empty()) throw std::runtime_error(ferr[i]);
             Tick t("upload + pack reads (H2D + device)");
-            const std::vector<u64> &off = foff[i];
-            const u64 n = off.size() - 1;
-            u64 lo = 0;                          // batches of ~256 MB of bases
-            while (lo < n) {
-                u64 hi = lo;
-                while (hi < n && off[hi + 1] - off[lo] < (256ull << 20)) ++hi;
-                if (hi == lo) ++hi;
-                d.chk(pb_reads_append(d.ctx, (const uint8_t *)fbases[i].data(), off.data() + lo, hi - lo, 1));
-                lo = hi;
+            for (ParsedPiece &pc : fpieces[i]) {
+                const std::vector<u64> &off = pc.off;
+                const u64 n = off.size() - 1;
+                u64 lo = 0;                          // batches of ~256 MB of bases
+                while (lo < n) {
+                    u64 hi = lo;
+                    while (hi < n && off[hi + 1] - off[lo] < (256ull << 20)) ++hi;
+                    if (hi == lo) ++hi;
+                    d.chk(pb_reads_append(d.ctx, (const uint8_t *)pc.bases.data(), off.data() + lo, hi - lo, 1));
+                    lo = hi;
+                }
             }
-            std::string().swap(fbases[i]);
-            std::vector<u64>().swap(foff[i]);
+            // returning ~0.5 GB per file to the kernel costs ~0.15 ms per MB: done by a helper thread, off the critical path
+            auto *dead = new std::vector<ParsedPiece>();
+            dead->swap(fpieces[i]);
+            reapers.emplace_back([dead]() { delete dead; });
         }
     }
     d.k.assign(1, opt.k0);
