@@ -456,7 +456,9 @@ void read_file(const std::string &path, std::vector<ParsedPiece> &pieces, unsign
     if (!fastq && data[0] != '>') throw std::runtime_error("Read file exception!!\nRead file is not FASTA/FASTQ format.");
     // cut points: the first line at or after i * size / n that starts with the record mark
     const char mark = fastq ? '@' : '>';
-    unsigned n = (unsigned)std::min<size_t>(std::max<unsigned>(max_threads, 1), size / (8u << 20) + 1);
+    size_t piece_bytes = 8u << 20;
+    if (const char *pb = getenv("PB_PARSE_PIECE_BYTES")) { const long v = atol(pb); if (v >= 64) piece_bytes = (size_t)v; }   // tests: tiny pieces
+    unsigned n = (unsigned)std::min<size_t>(std::max<unsigned>(max_threads, 1), size / piece_bytes + 1);
     std::vector<size_t> cut{0};
     for (unsigned i = 1; i < n; ++i) {
         size_t pos = size / n * i;

@@ -126,3 +126,63 @@ def test_cli_config3_full_multik_5mbp_md5(manifest, tmp_path):
         assert os.path.getsize(tmp_path / fn) == meta["bytes"], fn
         assert _md5(tmp_path / fn) == meta["md5"], fn
     print(f"config 3 incl. FASTQ generation: {time.time() - t0:.1f} s")
+
+
+def test_cli_piecewise_parser_equals_sequential_line_rules(manifest, tmp_path):
+    """The host reader cuts a file at lines that start with the record mark and parses the pieces in parallel; by the
+    reference's line rules (assemble.cpp:790-986) every such line is a restart point, so the result must not depend on the
+    cuts.  Inputs that stress the rules: quality lines that start with '@' or '+', sequences split over several lines,
+    empty lines, a header without sequence, no newline at the end of the file; FASTA with multi-line records.  The checker is
+    the real reference binary (oracle/_ref, when built) or the oracle's CLI with its own sequential reader; pieces of 4 KiB
+    force ~50 cuts per file."""
+    from platanus_b_amd import synth
+    oracle_bin = os.path.join(ROOT, "oracle", "_ref", "platanus_b")          # the real reference when it was built
+    extra = ["-t", "1"]
+    if not os.path.exists(oracle_bin):
+        oracle_bin, extra = os.path.join(ROOT, "oracle", "pb_oracle"), []
+    assert os.path.exists(oracle_bin)
+    r1, r2 = synth.make_reads(20_000, 30, seed=5, n_rate=0.001)
+    code2ascii = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    rng = np.random.default_rng(11)
+
+    def fastq(path, reads):
+        with open(path, "wb") as f:
+            for i, r in enumerate(reads):
+                seq = code2ascii[r].tobytes()
+                f.write(b"@r%d\n" % i)
+                if i % 7 == 3:                                   # sequence over three lines, with an empty line between
+                    f.write(seq[:50] + b"\n\n" + seq[50:90] + b"\n" + seq[90:] + b"\n")
+                else:
+                    f.write(seq + b"\n")
+                f.write(b"+\n")
+                q = bytearray(b"I" * len(seq))
+                if i % 5 == 1:
+                    q[0] = ord("@")                              # quality line that looks like a header
+                if i % 11 == 2:
+                    q[0] = ord("+")
+                f.write(bytes(q) + b"\n")
+                if i % 13 == 4:
+                    f.write(b"@orphan header without sequence\n+\n\n")
+            f.write(b"@last\n" + code2ascii[reads[0]].tobytes())   # no newline at the end of the file
+
+    def fasta(path, reads):
+        with open(path, "wb") as f:
+            for i, r in enumerate(reads):
+                seq = code2ascii[r].tobytes()
+                cut = int(rng.integers(10, 140))
+                f.write(b">s%d\n" % i + seq[:cut] + b"\n" + seq[cut:] + b"\n")
+
+    fastq(tmp_path / "a.fq", r1)
+    fasta(tmp_path / "b.fa", r2)
+    ref = tmp_path / "ref"
+    ref.mkdir()
+    p = subprocess.run([oracle_bin, "assemble", "-k", "32", *extra, "-o", "out", "-f", "../a.fq", "../b.fa"], cwd=ref, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    for piece in ("4096", "1000000000"):
+        got = tmp_path / ("gpu" + piece)
+        got.mkdir()
+        env = dict(os.environ, PB_PARSE_PIECE_BYTES=piece)
+        p = subprocess.run([BIN, "assemble", "-k", "32", "-o", "out", "-f", "../a.fq", "../b.fa"], cwd=got, capture_output=True, text=True, timeout=600, env=env)
+        assert p.returncode == 0, p.stderr[-2000:]
+        for fn in ("out_contig.fa", "out_32merFrq.tsv"):
+            assert filecmp.cmp(got / fn, ref / fn, shallow=False), (piece, fn)
