@@ -31,6 +31,7 @@ struct pb_ctx {
     int dev = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t lazy_ev[8] = {nullptr};          // LazyTimer: start / stop events of up to 4 stages that are read out later
     std::string err;
     std::map<std::string, float> stage_ms;
 
@@ -152,6 +153,26 @@ struct StageTimer {
     }
 };
 
+// Stage time without a host synchronisation per stage: the events are recorded on the stream and read after a later
+// synchronisation (LazyTimer::read).  slot 0..3.
+struct LazyTimer {
+    pb_ctx *ctx;
+    const char *name;
+    int slot;
+    LazyTimer(pb_ctx *c, const char *n, int s) : ctx(c), name(n), slot(s)
+    {
+        for (int i = 2 * s; i < 2 * s + 2; ++i) if (!ctx->lazy_ev[i]) (void)hipEventCreate(&ctx->lazy_ev[i]);
+        (void)hipEventRecord(ctx->lazy_ev[2 * s], ctx->stream);
+    }
+    void stop() { (void)hipEventRecord(ctx->lazy_ev[2 * slot + 1], ctx->stream); }
+    void read()                                  // after the stream has been synchronised past stop()
+    {
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, ctx->lazy_ev[2 * slot], ctx->lazy_ev[2 * slot + 1]);
+        ctx->stage_ms[name] = ms;
+    }
+};
+
 static inline unsigned grid_for(u64 n, unsigned block, unsigned max_blocks = 256 * 16)
 {
     u64 g = (n + block - 1) / block;
@@ -210,6 +231,7 @@ void pb_destroy(pb_ctx *ctx)
     for (int b = 0; b < 2; ++b) if (ctx->bounce[b]) { (void)hipHostFree(ctx->bounce[b]); (void)hipEventDestroy(ctx->bounce_ev[b]); }
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
+    for (auto &e : ctx->lazy_ev) if (e) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -517,35 +539,30 @@ static int count_superk(pb_ctx *ctx, unsigned k, bool *done)
         p.scalars = (u64 *)ctx->d_scalars.p;
         HIPCHK(hipMemsetAsync(ctx->d_scalars.p, 0, 16 * 8, ctx->stream));
         HIPCHK(hipMemsetAsync(ctx->part_meta.p, 0, (nb1 + 2 * nb2) * 4, ctx->stream));
+        LazyTimer ti(ctx, "table_init", 3);
+        table_init_kernel<1><<<grid_for(fcap * 2, 256, 256 * 32), 256, 0, ctx->stream>>>(p.fallback.slots, fcap);
+        ti.stop();
+        u64 sc[9];
         {
-            StageTimer ti(ctx, "table_init");
-            table_init_kernel<1><<<grid_for(fcap * 2, 256, 256 * 32), 256, 0, ctx->stream>>>(p.fallback.slots, fcap);
-            if ((rc = ti.stop()) != PB_OK) return rc;
-        }
-        {
-            StageTimer t1(ctx, "part1");
+            // one host synchronisation for the three kernels (the flags are needed before anything else is decided)
+            LazyTimer t1(ctx, "part1", 0);
             const u64 n_tiles = (ctx->stream_len + SK_OWN - 1) / SK_OWN;
             sk_part1_kernel<<<grid_for(n_tiles, 1, 256 * 8), SK_THREADS, 0, ctx->stream>>>((const u64 *)ctx->packed.p, cur_mask(ctx), ctx->stream_len,
                                                                                         (ctx->stream_len + 63) / 64 + PB_STREAM_PAD_WORDS64, p);
-            HIPCHK(hipGetLastError());
-            if ((rc = t1.stop()) != PB_OK) return rc;
-        }
-        {
-            StageTimer t2(ctx, "part2");
+            t1.stop();
+            LazyTimer t2(ctx, "part2", 1);
             // a few blocks per sub-stream, each striding over its tiles (most of cap1 is head-room: one block per tile would be mostly empty blocks)
             const u64 exp_tiles = (u64)(est_rec / (double)nb1) / SK2_RCAP + 1;
             const unsigned blocks_per_sub = (unsigned)std::min<u64>(std::max<u64>(exp_tiles / 4, 1), 64);
             sk_part2_kernel<<<dim3(blocks_per_sub, (unsigned)nb1), SK_THREADS, 0, ctx->stream>>>(p);
-            HIPCHK(hipGetLastError());
-            if ((rc = t2.stop()) != PB_OK) return rc;
-        }
-        u64 sc[9];
-        {
-            StageTimer t3(ctx, "bucket");
+            t2.stop();
+            LazyTimer t3(ctx, "bucket", 2);
             sk_bucket_kernel<<<grid_for(nb2, 1, 256 * 16), SK_ROLL_THREADS, 0, ctx->stream>>>(p, (u64 *)ctx->dist_keys.p, (u32 *)ctx->dist_counts.p, out_cap);
+            t3.stop();
             HIPCHK(hipGetLastError());
             HIPCHK(hipMemcpyAsync(sc, ctx->d_scalars.p, 72, hipMemcpyDeviceToHost, ctx->stream));
-            if ((rc = t3.stop()) != PB_OK) return rc;              // synchronises the stream
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            t1.read(); t2.read(); t3.read(); ti.read();
         }
         // sc[7] buckets had more distinct keys than an LDS table holds.  Many of them: the input is not the high-coverage kind
         // the bucket count was chosen for -- repeat with 4x the buckets rather than push a large share through the global table.
