@@ -26,6 +26,10 @@ def exchange_records(dist, torch, keys, counts, send_counts, W: int):
     Returns (recv_keys, recv_counts, recv_counts_per_rank)."""
     world = dist.get_world_size()
     dev = keys.device
+    if dev.type == "cuda" and dist.get_backend() == "gloo":
+        # gloo has no all_to_all on device tensors: stage through the host (tests: two ranks sharing one GPU)
+        rk, rcnt, recv = exchange_records(dist, torch, keys.cpu(), counts.cpu(), send_counts, W)
+        return rk.to(dev), rcnt.to(dev), recv
     sc = torch.tensor(send_counts, dtype=torch.int64, device=dev)
     rc = torch.empty(world, dtype=torch.int64, device=dev)
     dist.all_to_all_single(rc, sc)
@@ -59,13 +63,14 @@ def exchange_and_merge(g, dist, world: int, rank: int):
     hist = np.zeros(PB_OCC_BINS, dtype=np.uint64)
     mx, nd = C.c_uint64(), C.c_uint64()
     g._chk(lib.pb_merge_records(h, g.k, C.c_void_p(rk.data_ptr()), C.c_void_p(rcnt.data_ptr()), total, hist.ctypes.data, C.byref(mx), C.byref(nd)))
-    th = torch.from_numpy(hist.astype(np.int64)).to(dev)
+    red_dev = torch.device("cpu") if dist.get_backend() == "gloo" else dev
+    th = torch.from_numpy(hist.astype(np.int64)).to(red_dev)
     dist.all_reduce(th)
     ghist = th.cpu().numpy().astype(np.uint64)
     g.occ_hist = ghist
     nz = np.nonzero(ghist[1:65535])[0]
     g.max_occ = int(nz[-1]) + 1 if nz.size else 0
-    tn = torch.tensor([nd.value], dtype=torch.int64, device=dev)
+    tn = torch.tensor([nd.value], dtype=torch.int64, device=red_dev)
     dist.all_reduce(tn)
     g.n_distinct_local = nd.value
     g.n_distinct = int(tn.item())

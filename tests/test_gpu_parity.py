@@ -385,3 +385,35 @@ def test_merge_records_through_lds_tables(gpu, oracle_built, monkeypatch):
         g.retain(1)
         gk, gc = g.fetch_retained()
         assert np.array_equal(gk.reshape(-1), ok.reshape(-1)) and np.array_equal(gc, expect), table_path
+
+
+def test_two_ranks_share_one_gpu(oracle_built, tmp_path):
+    """The N > 1 step with real kernels: two processes on GPU 0 (gloo collectives staged through the host), each counting half
+    of the read pairs with the super-k-mer pass, exporting by owner, merging what it owns through the LDS-table merge.  The
+    all-reduced histogram and the union of the two owner shards must equal the single-process oracle on all reads."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    from platanus_b_amd import synth
+    k, genome, cov, seed = 31, 300_000, 40.0, 33
+    out = tmp_path / "res.json"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29551",
+           os.path.join(ROOT, "tests", "_gpu2_worker.py"), str(k), str(genome), str(cov), str(seed), str(out)]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    res = json.load(open(out))
+    assert res["superk"] and res["merged_lds"]
+    r1, r2 = synth.make_reads(genome, cov, seed, err=0.02)
+    codes = np.concatenate([r1, r2])
+    n, L = codes.shape
+    oc = _oracle(codes, np.arange(n + 1, dtype=np.uint64) * np.uint64(L), k, oracle_built)
+    ohist, _ = oc.occ_hist()
+    assert res["hist_nonzero"] == {str(int(i)): int(ohist[i]) for i in np.nonzero(ohist)[0]}
+    ok, ocn = oc.retain(1)
+    assert res["n_distinct"] == len(ok)
+    keys = np.concatenate([np.load(str(out) + f".keys{r}.npy").reshape(-1) for r in range(2)])
+    counts = np.concatenate([np.load(str(out) + f".counts{r}.npy") for r in range(2)])
+    order = np.argsort(keys, kind="stable")
+    assert np.array_equal(keys[order], ok.reshape(-1)) and np.array_equal(counts[order], ocn)
