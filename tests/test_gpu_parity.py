@@ -417,3 +417,49 @@ def test_two_ranks_share_one_gpu(oracle_built, tmp_path):
     counts = np.concatenate([np.load(str(out) + f".counts{r}.npy") for r in range(2)])
     order = np.argsort(keys, kind="stable")
     assert np.array_equal(keys[order], ok.reshape(-1)) and np.array_equal(counts[order], ocn)
+
+
+def test_superkmer_ragged_reads(gpu, oracle_built, monkeypatch):
+    """Reads of very different lengths in one stream: empty, shorter than k, exactly k, 150 bp, 20 kbp (longer than a kernel
+    tile, so its runs cross tile and lane boundaries), with N runs -- the super-k-mer path against the oracle."""
+    monkeypatch.setenv("PB_COUNT_PATH", "superk")
+    rng = np.random.default_rng(77)
+    genome = rng.integers(0, 4, 60_000).astype(np.uint8)
+    reads = []
+    for i in range(4000):
+        kind = i % 8
+        if kind == 0:
+            L = 0
+        elif kind == 1:
+            L = int(rng.integers(1, 31))
+        elif kind == 2:
+            L = 31
+        elif kind == 3:
+            L = 20_000 if i % 64 == 3 else 500
+        else:
+            L = 150
+        s = int(rng.integers(0, len(genome) - max(L, 1)))
+        r = genome[s:s + L].copy()
+        if rng.random() < 0.5:
+            r = (3 - r)[::-1]
+        if L >= 40 and kind == 4:
+            a = int(rng.integers(0, L - 8))
+            r[a:a + int(rng.integers(1, 8))] = 4                 # a short run of Ns
+        err = rng.random(L) < 0.01
+        r[err & (r < 4)] = (r[err & (r < 4)] + 1 + rng.integers(0, 3, int((err & (r < 4)).sum()))) & 3
+        reads.append(r)
+    lens = np.array([len(r) for r in reads], dtype=np.uint64)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    codes = np.concatenate(reads)
+    for k in (31, 20):
+        oc = _oracle(codes, off, k, oracle_built)
+        ohist, omax = oc.occ_hist()
+        g = gpu(0)
+        g.reads_append(codes, off)
+        hist = g.make_kmer_read_distribution(k)
+        assert g.kernel_ms("part1") > 0
+        assert np.array_equal(hist, ohist) and g.max_occ == omax, k
+        ok, ocn = oc.retain(1)
+        assert g.retain(1) == len(ok)
+        gk, gc = g.fetch_retained()
+        assert np.array_equal(gk, ok) and np.array_equal(gc, ocn), k
