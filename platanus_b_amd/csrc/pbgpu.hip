@@ -67,6 +67,7 @@ struct pb_ctx {
     u64 exp_cur[64] = {0};           // start of every owner's segment in the export (pb_export_begin -> pb_export_copy)
     u64 sk_records = 0;            // super-k-mer records of the last counting pass (0 = other path)
     u64 sk_flagged = 0, sk_spilled = 0, sk_extra_for = 0;
+    u64 hist_done = 0;              // leading records of the distinct arrays already tallied into d_hist
     unsigned sk_bits = 0, sk_extra_bits = 0;       // bucket bits used; extra bits that an earlier pass over the same stream needed
 
     // owner exchange (X1)
@@ -396,12 +397,15 @@ static int finish_count(pb_ctx *ctx, uint64_t *occ_hist, uint64_t *max_occ)
     // histogram of the distinct arrays (K4a) + copy out
     int rc;
     if ((rc = ensure(ctx, ctx->d_hist, 65536 * 8)) != PB_OK) return rc;
-    HIPCHK(hipMemsetAsync(ctx->d_hist.p, 0, 65536 * 8, ctx->stream));
-    {
+    // records [0, hist_done) were tallied into d_hist by the kernel that wrote them (sk_bucket_kernel's emit); the rest here
+    const u64 done = ctx->hist_done <= ctx->n_distinct ? ctx->hist_done : 0;
+    ctx->hist_done = 0;
+    if (done == 0) HIPCHK(hipMemsetAsync(ctx->d_hist.p, 0, 65536 * 8, ctx->stream));
+    ctx->stage_ms["hist"] = 0.f;
+    if (ctx->n_distinct > done) {
         StageTimer tm(ctx, "hist");
-        if (ctx->n_distinct)
-            hist_array_kernel<<<grid_for(ctx->n_distinct, 256, 256 * 8), 256, 0, ctx->stream>>>((const u32 *)ctx->dist_counts.p, ctx->n_distinct,
-                                                                                               (u64 *)ctx->d_hist.p);
+        hist_array_kernel<<<grid_for(ctx->n_distinct - done, 256, 256 * 8), 256, 0, ctx->stream>>>((const u32 *)ctx->dist_counts.p + done, ctx->n_distinct - done,
+                                                                                                  (u64 *)ctx->d_hist.p);
         HIPCHK(hipGetLastError());
         if ((rc = tm.stop()) != PB_OK) return rc;
     }
@@ -537,6 +541,9 @@ static int count_superk(pb_ctx *ctx, unsigned k, bool *done)
         ctx->table_cap = fcap;
         p.fallback = TableView<1>{(u64 *)ctx->table.p, fcap - 1};
         p.scalars = (u64 *)ctx->d_scalars.p;
+        if ((rc = ensure(ctx, ctx->d_hist, 65536 * 8)) != PB_OK) return rc;
+        p.hist = (u64 *)ctx->d_hist.p;
+        HIPCHK(hipMemsetAsync(ctx->d_hist.p, 0, 65536 * 8, ctx->stream));
         HIPCHK(hipMemsetAsync(ctx->d_scalars.p, 0, 16 * 8, ctx->stream));
         HIPCHK(hipMemsetAsync(ctx->part_meta.p, 0, (nb1 + 2 * nb2) * 4, ctx->stream));
         LazyTimer ti(ctx, "table_init", 3);
@@ -584,6 +591,7 @@ static int count_superk(pb_ctx *ctx, unsigned k, bool *done)
         if (sc[1] == 0) {
             ctx->n_instances = sc[0];
             ctx->n_distinct = sc[4];
+            ctx->hist_done = sc[4];                 // sk_bucket_kernel tallied its records while it wrote them
             ctx->sk_records = sc[6];
             ctx->sk_bits = B;
             ctx->sk_flagged = sc[7];
@@ -841,6 +849,7 @@ static int merge_records_lds(pb_ctx *ctx, const void *dev_keys, const void *dev_
     p.cursor2 = p.cursor1 + nb1;
     p.flag2 = p.cursor2 + nb2;
     p.fallback = TableView<1>{nullptr, 0};
+    p.hist = nullptr;
     p.scalars = (u64 *)ctx->d_scalars.p;
     if ((rc = ensure(ctx, ctx->dist_keys, n * 8)) != PB_OK) return rc;
     if ((rc = ensure(ctx, ctx->dist_counts, n * 4)) != PB_OK) return rc;
