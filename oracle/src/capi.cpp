@@ -362,3 +362,35 @@ extern "C" int pbo_replay_check(const uint8_t *codes, const unsigned long long *
         }
     } catch (...) { return -1; }
 }
+
+// ---- host-logic check without a GPU: the product's piece-wise parallel reader against the oracle's sequential one -------
+#include "fastx.hpp"
+#include "../../platanus_b_amd/host/read_files.hpp"
+
+extern "C" int pbo_parse_file_check(const char *path, unsigned max_threads, unsigned long long *n_reads, unsigned long long *n_pieces)
+{
+    try {
+        pbo::ReadSet rs;
+        pbo::read_fastx(path, rs);
+        std::vector<pbh::ParsedPiece> pieces;
+        pbh::read_file(path, pieces, max_threads);
+        static const unsigned char tab[16] = {46, 0, 46, 1, 3, 46, 46, 2, 46, 46, 46, 46, 46, 46, 4, 46};   // common.h:256, as the pack kernel applies it
+        u64 r = 0;
+        for (const pbh::ParsedPiece &pc : pieces) {
+            for (size_t i = 0; i + 1 < pc.off.size(); ++i, ++r) {
+                if (r + 1 >= rs.off.size()) return 1;                                  // more reads than the sequential reader found
+                const u64 len = pc.off[i + 1] - pc.off[i];
+                if (len != rs.off[r + 1] - rs.off[r]) return 2;
+                for (u64 j = 0; j < len; ++j) {
+                    unsigned c = tab[(unsigned char)pc.bases[pc.off[i] + j] & 0xF];
+                    if (c > 3) c = 4;
+                    if (c != rs.bases[rs.off[r] + j]) return 3;
+                }
+            }
+        }
+        if (r + 1 != rs.off.size()) return 4;
+        if (n_reads) *n_reads = r;
+        if (n_pieces) *n_pieces = pieces.size();
+        return 0;
+    } catch (...) { return -1; }
+}

@@ -1,0 +1,138 @@
+// Read ingest of `platanus_b assemble` on the host: the reference's FASTA/FASTQ line rules (assemble.cpp:790-986), applied to
+// pieces of a file in parallel.  Pure host code (no device calls): the oracle's test entry pbo_parse_file runs it on the CPU.
+#pragma once
+#include "kmer.hpp"
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+#include <sys/mman.h>
+#include <sys/stat.h>
+
+namespace pbh {
+
+// FASTA/FASTQ reader with the reference's line rules (assemble.cpp:790-986); bases are handed over as ASCII, the device
+// applies Char2Bin (common.h:256).  Sequence lines are appended straight into `bases` (the reference's `read += oneLine`
+// followed by the flush into the temp file).
+//
+// A plain file is parsed out of the page cache by several threads.  The reference's line rules make every line that starts
+// with the record mark ('@' / '>') a restart point: there the sequential parser flushes the read collected so far if it is
+// not empty and forgets everything else.  So the file is cut at such lines, every piece is parsed independently (flushing a
+// pending read at its end only if it is not empty), and the pieces in file order give exactly the sequential result; only
+// the last piece ends with the reference's unconditional trailing flush.
+struct ParsedPiece {
+    std::string bases;
+    std::vector<u64> off{0};
+};
+
+inline void parse_piece(const char *p, const char *end, bool fastq, bool first_piece, bool last_piece, ParsedPiece &out)
+{
+    std::string &bases = out.bases;
+    std::vector<u64> &off = out.off;
+    const char *ls = nullptr;
+    size_t len = 0;
+    auto next_line = [&]() -> bool {            // std::getline: a last line without '\n' counts, nothing after the final '\n'
+        if (p >= end) return false;
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+        ls = p;
+        len = (size_t)((nl ? nl : end) - p);
+        p = nl ? nl + 1 : end;
+        return true;
+    };
+    bases.reserve((size_t)(end - p) / 2 + 64);
+    u64 read_start = 0;                         // the current read = bases[read_start, bases.size())
+    auto flush = [&]() {
+        if (bases.size() - read_start >= 500000) throw std::runtime_error("Read file exception!!\nread length is too long");   // common.h:465-467
+        off.push_back(bases.size());
+        read_start = bases.size();
+    };
+    if (first_piece) next_line();               // the format line has been looked at by the caller; the reference consumes it the same way
+    if (fastq) {
+        bool flag = true;
+        while (next_line()) {
+            if (len == 0) continue;
+            if (ls[0] != '@') {
+                if (flag && ls[0] != '+') bases.append(ls, len); else flag = false;
+            } else {
+                if (bases.size() != read_start) flush();
+                flag = true;
+            }
+        }
+    } else {
+        while (next_line()) {
+            if (len == 0 || ls[0] != '>') bases.append(ls, len);
+            else if (bases.size() != read_start) flush();
+        }
+    }
+    if (last_piece || bases.size() != read_start) flush();     // the file's trailing read is written even when empty
+}
+
+inline void read_file(const std::string &path, std::vector<ParsedPiece> &pieces, unsigned max_threads)
+{
+    FILE *fp = nullptr;
+    bool piped = false;
+    const size_t L = path.size();
+    if (L > 3 && path.compare(L - 3, 3, ".gz") == 0) { fp = popen(("gzip -cd " + path).c_str(), "r"); piped = true; }
+    else if (L > 4 && path.compare(L - 4, 4, ".bz2") == 0) { fp = popen(("bzip2 -cd " + path).c_str(), "r"); piped = true; }
+    else fp = fopen(path.c_str(), "rb");
+    if (!fp) throw std::runtime_error("cannot open " + path);
+    std::string buf;
+    const char *data = nullptr;
+    size_t size = 0;
+    void *map = MAP_FAILED;
+    if (!piped) {                                 // plain file: parse straight out of the page cache
+        struct stat st;
+        if (fstat(fileno(fp), &st) == 0 && st.st_size > 0) {
+            map = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fileno(fp), 0);
+            if (map != MAP_FAILED) { data = (const char *)map; size = (size_t)st.st_size; madvise(map, size, MADV_WILLNEED); }
+        }
+    }
+    if (map == MAP_FAILED) {
+        std::vector<char> chunk(16u << 20);
+        size_t got;
+        while ((got = fread(chunk.data(), 1, chunk.size(), fp)) > 0) buf.append(chunk.data(), got);
+        data = buf.data();
+        size = buf.size();
+    }
+    if (piped) pclose(fp); else fclose(fp);
+    struct Unmap { void *m; size_t n; ~Unmap() { if (m != MAP_FAILED) munmap(m, n); } } unmap{map, size};
+    if (size == 0) throw std::runtime_error("empty read file " + path);
+    const bool fastq = data[0] == '@';
+    if (!fastq && data[0] != '>') throw std::runtime_error("Read file exception!!\nRead file is not FASTA/FASTQ format.");
+    // cut points: the first line at or after i * size / n that starts with the record mark
+    const char mark = fastq ? '@' : '>';
+    size_t piece_bytes = 8u << 20;
+    if (const char *pb = getenv("PB_PARSE_PIECE_BYTES")) { const long v = atol(pb); if (v >= 64) piece_bytes = (size_t)v; }   // tests: tiny pieces
+    unsigned n = (unsigned)std::min<size_t>(std::max<unsigned>(max_threads, 1), size / piece_bytes + 1);
+    std::vector<size_t> cut{0};
+    for (unsigned i = 1; i < n; ++i) {
+        size_t pos = size / n * i;
+        if (pos <= cut.back()) continue;
+        while (true) {                            // next line start
+            const char *nl = (const char *)memchr(data + pos, '\n', size - pos);
+            if (!nl) { pos = size; break; }
+            pos = (size_t)(nl - data) + 1;
+            if (pos >= size || data[pos] == mark) break;
+        }
+        if (pos < size && pos > cut.back()) cut.push_back(pos);
+    }
+    cut.push_back(size);
+    const size_t np = cut.size() - 1;
+    pieces.assign(np, ParsedPiece());
+    std::vector<std::string> err(np);
+    std::vector<std::thread> th;
+    for (size_t i = 0; i < np; ++i)
+        th.emplace_back([&, i]() {
+            try { parse_piece(data + cut[i], data + cut[i + 1], fastq, i == 0, i + 1 == np, pieces[i]); }
+            catch (const std::exception &e) { err[i] = e.what(); if (err[i].empty()) err[i] = "read error"; }
+        });
+    for (auto &t : th) t.join();
+    for (size_t i = 0; i < np; ++i) if (!err[i].empty()) throw std::runtime_error(err[i]);
+}
+
+
+} // namespace pbh
