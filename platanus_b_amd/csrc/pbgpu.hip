@@ -509,6 +509,7 @@ static int count_superk(pb_ctx *ctx, unsigned k, bool *done)
     for (int attempt = 0; attempt < 12; ++attempt) {
         p.B = B;
         p.l1 = B / 2;
+        if (const char *e = getenv("PB_SK_L1")) { const int v = atoi(e); if (v >= 1 && v < (int)B && v <= 9 && (int)B - v <= 9) p.l1 = (unsigned)v; }   // development
         p.l2 = B - p.l1;
         const int max_bases = (int)(123 - B) / 2;                 // 128 bits - 5 (length) - B (bucket), two bits per base
         int L = max_bases - (int)k + 1;
