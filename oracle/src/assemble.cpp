@@ -2,6 +2,7 @@
 // single-thread schedule.  Stage order and every floating-point expression follow the reference
 // literally: they decide the k schedule, the cutoffs and the coverage roundings.
 #include "assemble.hpp"
+#include "merge_run.hpp"
 #include "graph.hpp"
 #include "../../platanus_b_amd/host/schedule.hpp"
 #include <cfloat>
@@ -199,30 +200,49 @@ int run_assemble(const AssembleOptions &opt, const ReadSet &input)
     std::get<2>(run.graphs).set_thresholds(bubble, opt.branch);
     std::get<3>(run.graphs).set_thresholds(bubble, opt.branch);
     std::get<4>(run.graphs).set_thresholds(bubble, opt.branch);
-    if (opt.repeat) throw std::runtime_error("-repeat (merge of three cutoff passes) is outside the oracle's scope");
-
-    run.all_reads = input;
-    run.reads = input;
-    run.k.assign(1, opt.k0);
-    dispatch_w(opt.k0, [&](auto w) { run.template initial<decltype(w)::value>(0.0); });
-    if (opt.kmer_occ_only) {
-        if (opt.verbose) std::cerr << "assemble completed!" << std::endl;
-        return 0;
-    }
-    for (u64 i = 1; i < run.num_k; ++i) {
-        const unsigned kp = run.k[i - 1], kn = run.k[i];
-        dispatch_w(kp, [&](auto wp) {
-            dispatch_w(kn, [&](auto wn) {
-                constexpr int WP = decltype(wp)::value, WN = decltype(wn)::value;
-                if constexpr (WN >= WP) run.template save_and_redo<WP, WN>(kn, kp, i);
+    // assemble.cpp:148-240: -repeat runs the whole multi-k assembly three times with the coverage cutoff raised to 0, 1 and 2
+    // times the average coverage; the contigs of all passes are then merged through one more graph at the largest k reached
+    const int max_factor = opt.repeat ? 2 : 0;
+    unsigned max_k = 0;
+    for (int factor = 0; factor <= max_factor; ++factor) {
+        run.all_reads = input;
+        run.reads = input;
+        run.k.assign(1, opt.k0);
+        dispatch_w(opt.k0, [&](auto w) { run.template initial<decltype(w)::value>((double)factor); });
+        if (opt.kmer_occ_only) {
+            if (opt.verbose) std::cerr << "assemble completed!" << std::endl;
+            return 0;
+        }
+        for (u64 i = 1; i < run.num_k; ++i) {
+            const unsigned kp = run.k[i - 1], kn = run.k[i];
+            dispatch_w(kp, [&](auto wp) {
+                dispatch_w(kn, [&](auto wn) {
+                    constexpr int WP = decltype(wp)::value, WN = decltype(wn)::value;
+                    if constexpr (WN >= WP) run.template save_and_redo<WP, WN>(kn, kp, i);
+                });
             });
-        });
+        }
+        const unsigned klast = run.k[run.num_k - 1];
+        dispatch_w(klast, [&](auto w) { run.template output_and_after<decltype(w)::value>(klast); });
+        max_k = std::max(max_k, klast);
     }
-    const unsigned klast = run.k[run.num_k - 1];
-    dispatch_w(klast, [&](auto w) { run.template output_and_after<decltype(w)::value>(klast); });
     const std::string out = opt.out_prefix + "_contig.fa";
-    print_contigs(out, run.contigs, 1.0, run.avg_len, klast, "seq", false);
-    print_contigs(out, run.junctions, 1.0, run.avg_len, klast, "junction", true);
+    if (!opt.repeat) {
+        print_contigs(out, run.contigs, 1.0, run.avg_len, max_k, "seq", false);
+        print_contigs(out, run.junctions, 1.0, run.avg_len, max_k, "junction", true);
+    } else {
+        // mergeContig (assemble.cpp:270-295): Contig::readContigFP takes every seq record of the three passes as it was written
+        pbh::MergeContigs mc;
+        pbh::contig_records_to_pieces(run.contigs, mc);
+        const double merge_cov = pbh::merge_average_coverage(mc);
+        std::vector<ContigRecord> merged, merged_junctions;
+        dispatch_w(max_k, [&](auto w) {
+            constexpr int W = decltype(w)::value;
+            merge_contigs_into_graph<W>(run.template graph<W>(), mc, max_k, 1, run.memory, merge_cov, run.avg_len / (run.avg_len - max_k + 1.0), opt.verbose,
+                                        merged, merged_junctions);
+        });
+        print_contigs(out, merged, 1.0, run.avg_len, max_k, "seq", false);
+    }
     if (opt.verbose) std::cerr << "assemble completed!" << std::endl;
     return 0;
 }

@@ -4,6 +4,7 @@
 #include "fastx.hpp"
 #include "../../platanus_b_amd/host/kmer_divide.hpp"
 #include "../../platanus_b_amd/host/merge.hpp"
+#include "merge_run.hpp"
 #include "graph.hpp"
 #include <unordered_map>
 #include <cstdlib>
@@ -38,36 +39,10 @@ template <int W>
 static void oracle_merge_run(const pbh::MergeOptions &opt, const pbh::MergeContigs &mc, unsigned k, double avg_cov, pbo::u64 read_length)
 {
     using namespace pbo;
-    Counter<W> c;
-    c.k = k;
-    u64 total = 0;
-    for (const std::string &s : mc.seq) total += s.size() - k + 1;
-    const u64 upper = std::max(table_size_for_keys(total), table_size_for_memory(opt.memory_gb * 1000000000ull, W));
-    c.table.resize(upper);
-    for (size_t i = 0; i < mc.seq.size(); ++i) {                                    // counter.h:545-578
-        const u64 v = std::max<u64>(mc.coverage[i], opt.min_cov);
-        for_each_kmer<W>((const uint8_t *)mc.seq[i].data(), (unsigned)mc.seq[i].size(), k, [&](const Key<W> &key) {
-            const u64 s = c.table.find_any(key);
-            c.table.keys[s] = key;
-            if (c.table.vals[s] < v) c.table.vals[s] = (u16)v;
-        });
-    }
-    c.occ_hist.assign(65535, 0);
-    for (u64 s = 0; s < c.table.size(); ++s)                                        // writeKmerDistribution (counter.h:783-805)
-        if (c.table.vals[s] != 0) { c.kmer_keys.push_back(c.table.keys[s]); c.kmer_vals.push_back(c.table.vals[s]); ++c.occ_hist[c.table.vals[s]]; c.table.vals[s] = 0; }
-    c.find_max_occ();
-    std::vector<Key<W>> sorted = c.sorted_keys(0);
-    c.load_kmers(0, upper);
     Graph<W> g;
-    g.set_k(k);
     g.set_thresholds(atof(opt.bubble.c_str()), opt.branch);
-    g.make_initial(c.table, sorted);
-    c.table.release();
-    g.cut_branch_iterative(true);
-    g.crush_bubble_iterative(avg_cov, true);
     std::vector<ContigRecord> contigs, junctions;
-    g.save_contig_simple(contigs, 1.0);
-    g.save_junction(junctions, 1.0);
+    merge_contigs_into_graph<W>(g, mc, k, opt.min_cov, opt.memory_gb * 1000000000ull, avg_cov, 1.0, true, contigs, junctions);
     print_contigs(opt.out_prefix + "_merged.fa", contigs, 1.0, (double)read_length, (long)k, "seq", false);
     print_contigs(opt.out_prefix + "_mergedJunctionKmer.fa", junctions, 1.0, (double)read_length, (long)k, "junction", false);
 }

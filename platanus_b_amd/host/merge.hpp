@@ -84,6 +84,22 @@ inline double merge_average_coverage(const MergeContigs &mc)
     return static_cast<double>(sum) / num;
 }
 
+// Contig::readContigFP (common.h:774-800): the binary contig records of assemble's contigFP as pieces (-repeat's mergeContig).
+// RECORD has .seq (packed words, position p counts from the 3' end), .length, .cov.
+template <typename RECORD>
+inline void contig_records_to_pieces(const std::vector<RECORD> &recs, MergeContigs &mc)
+{
+    for (const RECORD &r : recs) {
+        std::string codes(r.length, 0);
+        for (u64 j = 0; j < r.length; ++j) {
+            const u64 p = r.length - 1 - j;
+            codes[j] = (char)((r.seq[p / 32] >> ((p % 32) * 2)) & 3);
+        }
+        mc.seq.push_back(codes);
+        mc.coverage.push_back((u16)r.cov);
+    }
+}
+
 inline u64 first_header_read_length(const std::string &path)        // common.h:686-701
 {
     std::ifstream ifs(path);

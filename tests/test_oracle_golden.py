@@ -101,3 +101,26 @@ def test_kmer_schedule(oracle_built):
                                       150.0, 1, 0.5, 32, 3, 10)
     assert ks[0] == 32 and ks[-1] == 75 and all(b > a for a, b in zip(ks, ks[1:]))
     assert cs[0] == 3 and cs[-1] == 1 and all(b <= a for a, b in zip(cs, cs[1:]))
+
+
+def test_repeat_mode_has_no_reference_output(tmp_path, oracle_built):
+    """`-repeat` is listed among the CLI options (assemble.cpp:55-70) but the reference binary built from v1.3.2 dies with
+    SIGSEGV in that mode on every input tried (here the 5 kbp case): the final stage's saveGraph runs
+    pickupReadMatchedEdgeKmer on a table of size 0.  The oracle restates the same control flow (three cutoff passes +
+    mergeContig) and dies at the same place.  So there is no reference output the device path could be identical to; it
+    rejects the option with an error instead."""
+    import signal
+    import subprocess
+    from conftest import ROOT
+    from platanus_b_amd import synth
+    synth.write_pair_files(str(tmp_path / "in"), 5000, 30, 3, err=0.01, n_rate=0.002)
+    bins = [os.path.join(ROOT, "oracle", "pb_oracle")]
+    ref = os.path.join(ROOT, "oracle", "_ref", "platanus_b")
+    if os.path.exists(ref):
+        bins.append(ref)
+    for b in bins:
+        p = subprocess.run([b, "assemble", "-k", "32", "-t", "1", "-m", "1", "-repeat", "-o", "out", "-f", "in_1.fq", "in_2.fq"], cwd=tmp_path,
+                           capture_output=True, text=True, timeout=300)
+        assert p.returncode == -signal.SIGSEGV, (b, p.returncode)
+        assert "extracting reads (containing kmer used in contig assemble)..." in p.stderr.splitlines()[-1]
+        assert not os.path.exists(tmp_path / "out_contig.fa")
