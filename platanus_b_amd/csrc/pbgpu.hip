@@ -511,10 +511,10 @@ static int count_superk(pb_ctx *ctx, unsigned k, bool *done)
         p.l1 = B / 2;
         if (const char *e = getenv("PB_SK_L1")) { const int v = atoi(e); if (v >= 1 && v < (int)B && v <= 9 && (int)B - v <= 9) p.l1 = (unsigned)v; }   // development
         p.l2 = B - p.l1;
-        const int max_bases = (int)(123 - B) / 2;                 // 128 bits - 5 (length) - B (bucket), two bits per base
+        const int max_bases = 32 + (int)(29 - B) / 2;             // 96 bits: 32 bases + (32 - 3 (length - 1) - B (bucket)) / 2 more
         int L = max_bases - (int)k + 1;
         if (L > SK_LCAP) L = SK_LCAP;
-        if (const char *lc = getenv("PB_SK_LCAP")) { const int v = atoi(lc); if (v >= 1 && v < 32 && v <= max_bases - (int)k + 1) L = v; }
+        if (const char *lc = getenv("PB_SK_LCAP")) { const int v = atoi(lc); if (v >= 1 && v <= SK_LCAP && v <= max_bases - (int)k + 1) L = v; }
         if (L < 1) return PB_OK;
         p.L = (unsigned)L;
         // expected windows per record: a new minimizer every (w+1)/2 windows, a forced start every L
@@ -523,14 +523,14 @@ static int count_superk(pb_ctx *ctx, unsigned k, bool *done)
         const u64 nb1 = (1ull << p.l1) * PB_XCD, nb2 = 1ull << B;
         p.cap1 = (u64)(est_rec / (double)nb1 * 1.5) + 4096;
         p.cap2 = (u32)std::min<double>(est_rec / (double)nb2 * 3.0 + 256.0, 1e9);   // minimizer sites are few per bucket: sizes vary a lot
-        if ((rc = ensure(ctx, ctx->part_bucket1, nb1 * p.cap1 * sizeof(SkRec))) != PB_OK) return rc;
-        if ((rc = ensure(ctx, ctx->part_bucket2, nb2 * (u64)p.cap2 * sizeof(SkRec))) != PB_OK) return rc;
+        if ((rc = ensure(ctx, ctx->part_bucket1, nb1 * p.cap1 * SkStore12::BYTES)) != PB_OK) return rc;
+        if ((rc = ensure(ctx, ctx->part_bucket2, (nb2 * (u64)p.cap2 + 1024) * SkStore12::BYTES)) != PB_OK) return rc;
         if ((rc = ensure(ctx, ctx->part_meta, (nb1 + 2 * nb2) * 4)) != PB_OK) return rc;
         p.spill_cap = std::max<u64>((u64)(est_rec / 16), 1ull << 16);
-        if ((rc = ensure(ctx, ctx->part_spill, p.spill_cap * sizeof(SkRec))) != PB_OK) return rc;
-        p.spill = (SkRec *)ctx->part_spill.p;
-        p.bucket1 = (SkRec *)ctx->part_bucket1.p;
-        p.bucket2 = (SkRec *)ctx->part_bucket2.p;
+        if ((rc = ensure(ctx, ctx->part_spill, p.spill_cap * SkStore12::BYTES)) != PB_OK) return rc;
+        p.spill = ctx->part_spill.p;
+        p.bucket1 = ctx->part_bucket1.p;
+        p.bucket2 = ctx->part_bucket2.p;
         p.cursor1 = (u32 *)ctx->part_meta.p;
         p.cursor2 = p.cursor1 + nb1;
         p.flag2 = p.cursor2 + nb2;
@@ -562,7 +562,7 @@ static int count_superk(pb_ctx *ctx, unsigned k, bool *done)
             // a few blocks per sub-stream, each striding over its tiles (most of cap1 is head-room: one block per tile would be mostly empty blocks)
             const u64 exp_tiles = (u64)(est_rec / (double)nb1) / SK2_RCAP + 1;
             const unsigned blocks_per_sub = (unsigned)std::min<u64>(std::max<u64>(exp_tiles / 4, 1), 64);
-            sk_part2_kernel<<<dim3(blocks_per_sub, (unsigned)nb1), SK_THREADS, 0, ctx->stream>>>(p);
+            sk_part2_kernel<SkStore12><<<dim3(blocks_per_sub, (unsigned)nb1), SK_THREADS, 0, ctx->stream>>>(p);
             t2.stop();
             LazyTimer t3(ctx, "bucket", 2);
             sk_bucket_kernel<<<grid_for(nb2, 1, 256 * 16), SK_ROLL_THREADS, 0, ctx->stream>>>(p, (u64 *)ctx->dist_keys.p, (u32 *)ctx->dist_counts.p, out_cap);
@@ -843,9 +843,9 @@ static int merge_records_lds(pb_ctx *ctx, const void *dev_keys, const void *dev_
     if ((rc = ensure(ctx, ctx->part_meta, (nb1 + 2 * nb2) * 4)) != PB_OK) return rc;
     p.spill_cap = 1ull << 16;
     if ((rc = ensure(ctx, ctx->part_spill, p.spill_cap * sizeof(SkRec))) != PB_OK) return rc;
-    p.spill = (SkRec *)ctx->part_spill.p;
-    p.bucket1 = (SkRec *)ctx->part_bucket1.p;
-    p.bucket2 = (SkRec *)ctx->part_bucket2.p;
+    p.spill = ctx->part_spill.p;
+    p.bucket1 = ctx->part_bucket1.p;
+    p.bucket2 = ctx->part_bucket2.p;
     p.cursor1 = (u32 *)ctx->part_meta.p;
     p.cursor2 = p.cursor1 + nb1;
     p.flag2 = p.cursor2 + nb2;
@@ -859,7 +859,7 @@ static int merge_records_lds(pb_ctx *ctx, const void *dev_keys, const void *dev_
     StageTimer tm(ctx, "merge");
     mg_part1_kernel<<<grid_for((n + SK2_RCAP - 1) / SK2_RCAP, 1, 256 * 8), SK_THREADS, 0, ctx->stream>>>((const u64 *)dev_keys, (const u32 *)dev_counts, n, p);
     const u64 exp_tiles = n / nb1 / SK2_RCAP + 1;
-    sk_part2_kernel<<<dim3((unsigned)std::min<u64>(std::max<u64>(exp_tiles / 4, 1), 64), (unsigned)nb1), SK_THREADS, 0, ctx->stream>>>(p);
+    sk_part2_kernel<SkStore16><<<dim3((unsigned)std::min<u64>(std::max<u64>(exp_tiles / 4, 1), 64), (unsigned)nb1), SK_THREADS, 0, ctx->stream>>>(p);
     mg_bucket_kernel<<<grid_for(nb2, 1, 256 * 16), SK_ROLL_THREADS, 0, ctx->stream>>>(p, (u64 *)ctx->dist_keys.p, (u32 *)ctx->dist_counts.p, n);
     HIPCHK(hipGetLastError());
     u64 sc[9];

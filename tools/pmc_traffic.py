@@ -17,7 +17,8 @@ def load(path, counter):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         if r.get("Counter_Name") == counter:
-            acc[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]) * 1024.0)
+            name = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]      # "void sk_part2_kernel<SkStore12>(SkParams)"
+            acc[name].append(float(r["Counter_Value"]) * 1024.0)
     return acc
 
 
