@@ -62,6 +62,7 @@ struct pb_ctx {
     hipEvent_t bounce_ev[2];
     bool bounce_used[2] = {false, false};
     std::vector<u64> rel_keep[2];
+    hipEvent_t rel_ev[2] = {nullptr, nullptr};
     int rel_next = 0;
     int bounce_next = 0;
     u64 exp_cur[64] = {0};           // start of every owner's segment in the export (pb_export_begin -> pb_export_copy)
@@ -233,6 +234,7 @@ void pb_destroy(pb_ctx *ctx)
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
     for (auto &e : ctx->lazy_ev) if (e) (void)hipEventDestroy(e);
+    for (auto &e : ctx->rel_ev) if (e) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -355,13 +357,17 @@ int pb_reads_append(pb_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, 
     if ((rc = ensure(ctx, d_bases, n_new_bases + 16)) != PB_OK) return rc;
     if ((rc = ensure(ctx, d_off, (n_reads + 1) * 8)) != PB_OK) return rc;
     // offsets relative to this batch; the vector stays alive in the context until two calls later (the copy below may read it
-    // asynchronously; a later bounce-buffer wait in upload_bases, or the stream synchronisation for small batches, covers it)
-    std::vector<u64> &rel = ctx->rel_keep[ctx->rel_next];
+    // asynchronously: an event recorded behind the copy is waited for before the vector is written again)
+    const int rslot = ctx->rel_next;
     ctx->rel_next ^= 1;
+    if (!ctx->rel_ev[rslot]) HIPCHK(hipEventCreateWithFlags(&ctx->rel_ev[rslot], hipEventDisableTiming));
+    else HIPCHK(hipEventSynchronize(ctx->rel_ev[rslot]));        // the copy that last read this vector is done
+    std::vector<u64> &rel = ctx->rel_keep[rslot];
     rel.resize(n_reads + 1);
     for (u64 r = 0; r <= n_reads; ++r) rel[r] = offsets[r] - offsets[0];
     lap("rel");
     HIPCHK(hipMemcpyAsync(d_off.p, rel.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipEventRecord(ctx->rel_ev[rslot], ctx->stream));
     if ((rc = upload_bases(ctx, (unsigned char *)d_bases.p, bases + offsets[0], n_new_bases)) != PB_OK) return rc;
     if (n_new_bases < (4ull << 20)) HIPCHK(hipStreamSynchronize(ctx->stream));
     lap("upload");
