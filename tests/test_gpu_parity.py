@@ -463,3 +463,14 @@ def test_superkmer_ragged_reads(gpu, oracle_built, monkeypatch):
         assert g.retain(1) == len(ok)
         gk, gc = g.fetch_retained()
         assert np.array_equal(gk, ok) and np.array_equal(gc, ocn), k
+
+
+def test_superkmer_random_differential():
+    """tools/fuzz_count.py: random genomes (with low-complexity inserts), coverages, error / N rates, mixed read lengths, k in
+    1..32 and forced bucket counts -- the super-k-mer pass and the direct pass must agree on histogram, keys and counts."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_count.py"), "24", "11"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "24 cases, 0 mismatches" in p.stdout
