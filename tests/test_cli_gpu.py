@@ -186,3 +186,12 @@ def test_cli_piecewise_parser_equals_sequential_line_rules(manifest, tmp_path):
         assert p.returncode == 0, p.stderr[-2000:]
         for fn in ("out_contig.fa", "out_32merFrq.tsv"):
             assert filecmp.cmp(got / fn, ref / fn, shallow=False), (piece, fn)
+
+
+def test_cli_random_differential_against_oracle_cli():
+    """tools/fuzz_cli.py: random small genomes with copied, inverted and tandem repeats (junctions, hairpins and cycles in the
+    graph), random k / step / -u / -n: every output file of the GPU CLI must be byte-identical to the oracle CLI's."""
+    import sys
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_cli.py"), "10", "21"], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+    assert "10 cases, 0 mismatches" in p.stdout

@@ -1,0 +1,85 @@
+"""Development aid: differential test of the whole `assemble` CLI (GPU build) against the oracle's CLI on random small inputs
+with repeats, inverted repeats and tandem repeats (junctions, hairpins, cycles in the graph) and random options.
+usage: python tools/fuzz_cli.py [n_cases] [seed]"""
+import filecmp
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+GPU = os.path.join(ROOT, "platanus_b_amd", "bin", "platanus_b")
+ORC = os.path.join(ROOT, "oracle", "pb_oracle")
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    asc = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    bad = 0
+    for case in range(n_cases):
+        G = int(rng.integers(3_000, 40_000))
+        g = rng.integers(0, 4, G).astype(np.uint8)
+        for _ in range(int(rng.integers(0, 6))):               # repeats: copy, inverted copy, tandem
+            L = int(rng.integers(40, 600))
+            a, b = int(rng.integers(0, G - L)), int(rng.integers(0, G - L))
+            kind = int(rng.integers(0, 3))
+            if kind == 0:
+                g[b:b + L] = g[a:a + L]
+            elif kind == 1:
+                g[b:b + L] = (3 - g[a:a + L])[::-1]
+            else:
+                unit = g[a:a + int(rng.integers(2, 40))]
+                g[b:b + L] = np.resize(unit, L)
+        cov = float(rng.choice([15, 30, 60]))
+        err = float(rng.choice([0.0, 0.003, 0.01]))
+        RL = int(rng.choice([100, 125, 150]))
+        n_pairs = int(G * cov) // (2 * RL)
+        with tempfile.TemporaryDirectory() as td:
+            for mate in (1, 2):
+                with open(os.path.join(td, f"in_{mate}.fq"), "wb") as f:
+                    for i in range(n_pairs):
+                        fl = int(np.clip(rng.normal(350, 30), RL, G))
+                        s = int(rng.integers(0, G - fl + 1))
+                        frag = g[s:s + fl]
+                        r = frag[:RL].copy() if mate == 1 else (3 - frag[-RL:])[::-1].copy()
+                        e = rng.random(RL) < err
+                        r[e] = (r[e] + 1 + rng.integers(0, 3, int(e.sum()))) & 3
+                        if rng.random() < 0.02:
+                            r[int(rng.integers(0, RL))] = 4
+                        f.write(b"@r%d/%d\n" % (i, mate) + asc[r].tobytes() + b"\n+\n" + b"I" * RL + b"\n")
+            k = int(rng.choice([21, 25, 32, 33, 40, 45]))
+            args = ["-k", str(k), "-s", str(int(rng.choice([0, 5, 10, 20]))), "-u", str(rng.choice(["0", "0", "1"])), "-m", "1"]
+            if rng.random() < 0.3:
+                args += ["-n", str(int(rng.integers(1, 4)))]
+            outs = {}
+            for name, binary, extra in (("orc", ORC, []), ("gpu", GPU, [])):
+                d = os.path.join(td, name)
+                os.mkdir(d)
+                p = subprocess.run([binary, "assemble", *args, *extra, "-o", "out", "-f", "../in_1.fq", "../in_2.fq"], cwd=d, capture_output=True, text=True,
+                                   timeout=600)
+                outs[name] = (p.returncode, d)
+            same = outs["orc"][0] == outs["gpu"][0]
+            if same and outs["orc"][0] == 0:
+                for fn in sorted(os.listdir(outs["orc"][1])):
+                    if not fn.startswith("out_"):
+                        continue
+                    a, b = os.path.join(outs["orc"][1], fn), os.path.join(outs["gpu"][1], fn)
+                    if not os.path.exists(b) or not filecmp.cmp(a, b, shallow=False):
+                        same = False
+                        print(f"  differs: {fn}")
+            if not same:
+                bad += 1
+                print(f"MISMATCH case {case}: G={G} cov={cov} err={err} RL={RL} args={' '.join(args)} rc={outs['orc'][0]}/{outs['gpu'][0]}", flush=True)
+            else:
+                nct = sum(1 for l in open(os.path.join(outs["gpu"][1], "out_contig.fa")) if l.startswith(">")) if outs["gpu"][0] == 0 else -1
+                print(f"case {case}: ok (G={G} cov={cov} err={err} args={' '.join(args)} rc={outs['gpu'][0]} records={nct})", flush=True)
+    print(f"{n_cases} cases, {bad} mismatches")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
