@@ -675,7 +675,7 @@ int pb_retain(pb_ctx *ctx, unsigned min_occ, uint64_t *n_keys)
     {
         StageTimer tm(ctx, "filter");
         if (nd)
-            filter_array_kernel<<<grid_for(nd, 256, 256 * 8), 256, 0, ctx->stream>>>((const u64 *)ctx->dist_keys.p, (const u32 *)ctx->dist_counts.p, nd, W,
+            filter_array_kernel<<<grid_for(nd, 256 * FLT_RPT, 256 * 8), 256, 0, ctx->stream>>>((const u64 *)ctx->dist_keys.p, (const u32 *)ctx->dist_counts.p, nd, W,
                                                                                      min_occ, (u64 *)ck.p, (u32 *)cc.p, (u64 *)ctx->d_scalars.p);
         HIPCHK(hipGetLastError());
         if ((rc = tm.stop()) != PB_OK) return rc;

@@ -43,23 +43,40 @@ def main():
         off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
         codes = np.concatenate(reads)
         res = {}
-        for path in ("direct", "superk"):
+        skb = str(int(rng.integers(2, 19))) if rng.random() < 0.5 else None
+
+        def run(path):
             os.environ["PB_COUNT_PATH"] = path
-            if path == "superk" and rng.random() < 0.5:
-                os.environ["PB_FORCE_SKB"] = str(int(rng.integers(2, 19)))
+            if path == "superk" and skb:
+                os.environ["PB_FORCE_SKB"] = skb
             g = GpuCounter(0)
             g.reads_append(codes, off)
             hist = g.make_kmer_read_distribution(k)
             took = g.kernel_ms("part1") > 0
             g.retain(1)
             keys, counts = g.fetch_retained()
-            res[path] = (hist.copy(), keys.copy(), counts.copy(), g.n_instances, took)
+            out = (hist.copy(), keys.copy(), counts.copy(), g.n_instances, took)
             g.close()
             os.environ.pop("PB_FORCE_SKB", None)
+            return out
+
+        for path in ("direct", "superk"):
+            res[path] = run(path)
         d, s_ = res["direct"], res["superk"]
         ok = np.array_equal(d[0], s_[0]) and np.array_equal(d[1], s_[1]) and np.array_equal(d[2], s_[2]) and d[3] == s_[3]
         if not ok:
             bad += 1
+            for path in ("direct", "superk"):                  # which side is unstable, and how?
+                for rep in range(3):
+                    o = run(path)
+                    print(f"    rerun {path} {rep}: equals first run of direct {np.array_equal(o[1], d[1]) and np.array_equal(o[2], d[2]) and np.array_equal(o[0], d[0])}, of superk "
+                          f"{np.array_equal(o[1], s_[1]) and np.array_equal(o[2], s_[2]) and np.array_equal(o[0], s_[0])}  n_keys {len(o[1])} skb={skb}")
+            ka, kb = d[1].reshape(len(d[2]), -1)[:, 0], s_[1].reshape(len(s_[2]), -1)[:, 0]
+            only_a, only_b = np.setdiff1d(ka, kb), np.setdiff1d(kb, ka)
+            print(f"    keys only in direct {len(only_a)} {only_a[:4]}, only in superk {len(only_b)} {only_b[:4]}")
+            if len(ka) == len(kb) and np.array_equal(ka, kb):
+                diff = np.nonzero(d[2] != s_[2])[0]
+                print(f"    same keys; counts differ at {len(diff)} places: {[(hex(int(ka[i])), int(d[2][i]), int(s_[2][i])) for i in diff[:6]]}")
             print(f"MISMATCH case {case}: G={G} cov={cov} err={err} n={n_rate} k={k} reads={len(reads)} instances {d[3]} vs {s_[3]} distinct {len(d[1])} vs {len(s_[1])}", flush=True)
         elif case % 10 == 0:
             print(f"case {case}: ok (G={G} cov={cov} k={k} reads={len(reads)} instances={d[3]} distinct={len(d[1])} superk={s_[4]})", flush=True)
