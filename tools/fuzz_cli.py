@@ -1,6 +1,6 @@
 """Development aid: differential test of the whole `assemble` CLI (GPU build) against the oracle's CLI on random small inputs
 with repeats, inverted repeats and tandem repeats (junctions, hairpins, cycles in the graph) and random options.
-usage: python tools/fuzz_cli.py [n_cases] [seed]"""
+usage: python tools/fuzz_cli.py [n_cases] [seed] [min_genome] [max_genome]     (>= ~110 kbp at 40x reaches the super-k-mer pass)"""
 import filecmp
 import os
 import subprocess
@@ -18,10 +18,12 @@ ORC = os.path.join(ROOT, "oracle", "pb_oracle")
 def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    g_lo = int(sys.argv[3]) if len(sys.argv) > 3 else 3_000
+    g_hi = int(sys.argv[4]) if len(sys.argv) > 4 else 40_000
     asc = np.frombuffer(b"ACGTN", dtype=np.uint8)
     bad = 0
     for case in range(n_cases):
-        G = int(rng.integers(3_000, 40_000))
+        G = int(rng.integers(g_lo, g_hi))
         g = rng.integers(0, 4, G).astype(np.uint8)
         for _ in range(int(rng.integers(0, 6))):               # repeats: copy, inverted copy, tandem
             L = int(rng.integers(40, 600))
