@@ -154,6 +154,53 @@ def test_full_size_properties(gpu):
     assert np.array_equal(k1, k3) and np.array_equal(c1, c3)
 
 
+def test_config2_full_size_through_the_cabi(gpu, manifest, tmp_path, monkeypatch):
+    """BASELINE configs[1] at its full size (5 Mbp x 100x PE150, k = 32: 396.7 M windows, 60.8 M distinct 32-mers) through
+    the C-ABI.  The oracle needs minutes here, so the checks are (1) the occurrence distribution written as the reference
+    writes it (counter.h:999-1007) against the md5 of the REAL reference's PREFIX_32merFrq.tsv for this input
+    (tests/golden/manifest.json, cfg3), (2) sum(hist) = distinct and sum(i*hist) = windows, (3) strand invariance: the
+    reverse complements of all reads give the same retained (key,count) table (keys are canonical, counter.h:429),
+    (4) the direct global-table pass and the super-k-mer pass agree on that table."""
+    import hashlib
+    from platanus_b_amd import synth
+    case = manifest["cfg3"]
+    G, cov, seed = case["genome"], case["cov"], case["seed"]
+    genome = synth.make_genome(G, seed)
+    n_pairs = int(G * cov) // 300
+    g, grc = gpu(0), gpu(0)
+    for lo in range(0, n_pairs, 250_000):
+        r1, r2 = synth.make_reads(G, cov, seed, genome=genome, pair_lo=lo, pair_hi=min(lo + 250_000, n_pairs), err=case["err"])
+        g.reads_append_matrix(r1)
+        g.reads_append_matrix(r2)
+        grc.reads_append_matrix(np.ascontiguousarray(3 - r2[:, ::-1]))
+        grc.reads_append_matrix(np.ascontiguousarray(3 - r1[:, ::-1]))
+    h = g.make_kmer_read_distribution(32).copy()
+    assert g.kernel_ms("part1") > 0                          # the super-k-mer pass took it
+    n_reads, _ = g.reads_info()
+    assert n_reads == 2 * n_pairs and g.n_instances == n_reads * 119
+    assert int(h.sum()) == g.n_distinct
+    assert int((np.arange(65535, dtype=np.uint64) * h).sum()) == g.n_instances
+    out = tmp_path / "out_32merFrq.tsv"
+    g.output_occurrence_distribution(str(out))
+    assert hashlib.md5(open(out, "rb").read()).hexdigest() == case["runs"]["multik"]["files"]["out_32merFrq.tsv"]["md5"]
+    n = g.retain(3)
+    keys, counts = g.fetch_retained()
+    assert n == len(counts) and (keys[1:, 0] > keys[:-1, 0]).all()
+    hrc = grc.make_kmer_read_distribution(32)
+    assert np.array_equal(h, hrc)
+    grc.retain(3)
+    krc, crc = grc.fetch_retained()
+    assert np.array_equal(keys, krc) and np.array_equal(counts, crc)
+    del grc
+    monkeypatch.setenv("PB_COUNT_PATH", "direct")
+    hd = g.make_kmer_read_distribution(32)
+    assert g.kernel_ms("part1") == 0
+    assert np.array_equal(h, hd)
+    g.retain(3)
+    kd, cd = g.fetch_retained()
+    assert np.array_equal(keys, kd) and np.array_equal(counts, cd)
+
+
 @pytest.mark.parametrize("k", [32, 45])
 def test_export_buckets_and_merge_roundtrip(k, gpu, oracle_built):
     """X1 on one GPU: bucket the table into 8 owner parts, check every record sits in its owner's bucket, merge the
