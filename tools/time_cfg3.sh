@@ -1,0 +1,17 @@
+#!/bin/bash
+# development: stage times of the device CLI on BASELINE configs[2] (5 Mbp x 100x, full multi-k)
+set -e
+D=$(mktemp -d /tmp/cfg3_XXXX)
+python3 -c "
+import sys; sys.path.insert(0,'.')
+from platanus_b_amd import synth
+synth.write_pair_files('$D/in', 5_000_000, 100, 1)
+"
+for i in 1 2 3; do
+  t0=$(date +%s.%N)
+  PB_TIMING=1 platanus_b_amd/bin/platanus_b assemble -k 32 -o $D/out -f $D/in_1.fq $D/in_2.fq 2> $D/log$i > /dev/null
+  echo "run $i: wall $(echo "$(date +%s.%N) - $t0" | bc) s"
+done
+sed -n "/STAGE WALL/,\$p" $D/log3
+md5sum $D/out_contig.fa $D/out_32merFrq.tsv
+rm -rf "$D"
