@@ -45,8 +45,10 @@ static StageClock g_clock;
 struct Tick {
     std::string name;
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    bool live = true;
     explicit Tick(const std::string &n) : name(n) {}
-    ~Tick() { g_clock.add(name, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count()); }
+    void stop() { if (live) g_clock.add(name, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count()); live = false; }
+    ~Tick() { stop(); }
 };
 
 struct Driver {
@@ -62,12 +64,29 @@ struct Driver {
     std::vector<u64> occ_hist = std::vector<u64>(PB_OCC_BINS);
     u64 max_occ = 0;
 
+    // The device context (HIP runtime start-up, ~0.2 s) is created on a helper thread while the input files are parsed.
+    std::thread creator;
+    int create_rc = PB_OK;
+    double create_s = 0;
     explicit Driver(const GpuAssembleOptions &o) : opt(o)
     {
-        const int rc = pb_create(o.device, &ctx);
-        if (rc != PB_OK) throw GpuError(rc, std::string("libpbgpu: ") + pb_last_error(nullptr));
+        creator = std::thread([this]() {
+            const auto t0 = std::chrono::steady_clock::now();
+            create_rc = pb_create(opt.device, &ctx);
+            create_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        });
     }
-    ~Driver() { pb_destroy(ctx); }
+    void ready()                                   // before the first call that takes ctx
+    {
+        if (!creator.joinable()) return;
+        creator.join();
+        if (create_rc != PB_OK) throw GpuError(create_rc, std::string("libpbgpu: ") + pb_last_error(nullptr));
+    }
+    ~Driver()
+    {
+        if (creator.joinable()) creator.join();
+        pb_destroy(ctx);
+    }
     void chk(int rc) const { if (rc != PB_OK) throw GpuError(rc, std::string("libpbgpu: ") + pb_last_error(ctx)); }
     template <int W> Graph<W> &graph() { return std::get<W - 1>(graphs); }
     void log(const std::string &s) const { if (opt.verbose) std::cerr << s << std::endl; }
@@ -162,7 +181,10 @@ struct Driver {
         avg_cov = dist_average(occ_hist, cutoff[0], max_occ);
         if (opt.expected_cov != "") avg_cov = atof(opt.expected_cov.c_str());
         std::vector<u64> len_hist(500001);
-        chk(pb_reads_length_hist(ctx, len_hist.data(), len_hist.size()));
+        {
+            Tick t("read length histogram (device)");
+            chk(pb_reads_length_hist(ctx, len_hist.data(), len_hist.size()));
+        }
         avg_len = dist_average(len_hist, 0, 500000);
         avg_cov = avg_cov * avg_len / (avg_len - k[0] + 1.0);
         if (opt.verbose) std::cerr << "AVE_READ_LEN=" << avg_len << std::endl;
@@ -277,9 +299,11 @@ struct Driver {
     template <int W> void save_graph(unsigned graph_k, unsigned next_k)
     {
         std::vector<u64> edge;
+        Tick t0("edge k-mers (host)");
         graph<W>().save_edge_kmers([&](const Key<W> &key, u16) { for (int w = 0; w < W; ++w) edge.push_back(key.w[w]); }, next_k);
         log("extracting reads (containing kmer used in contig assemble)...");
         u64 kept = 0;
+        t0.stop();
         Tick t("read filter (device)");
         chk(pb_reads_filter(ctx, graph_k, edge.data(), edge.size() / W, &kept));
     }
@@ -290,13 +314,15 @@ struct Driver {
         std::vector<uint8_t> bases;
         std::vector<u64> off{0};
         std::vector<u16> vals;
+        Tick t0("contig strings (host)");
         graph<WP>().for_each_contig_string(next_k, ratio, [&](const std::vector<unsigned char> &str, u16 occ) {
             bases.insert(bases.end(), str.begin(), str.end());
             off.push_back(bases.size());
             vals.push_back(occ);
         });
         u64 nw = 0;
-        Tick t("contig table (host strings + device)");
+        t0.stop();
+        Tick t("contig table (device)");
         chk(pb_contig_table_build(ctx, next_k, bases.data(), off.data(), vals.data(), vals.size(), &nw));
     }
 
@@ -320,7 +346,10 @@ struct Driver {
     {
         save_graph<WP>(prev_k, kk);
         contig_table<WP>(kk, (avg_len - kk + 1.0) / (avg_len - prev_k + 1.0));
-        graph<WP>().delete_all();
+        {
+            Tick t("graph reset (host)");
+            graph<WP>().delete_all();
+        }
         if (opt.verbose) std::cerr << "K = " << kk << ", loading kmers from contigs..." << std::endl;
         redo<WN>(kk, position);
     }
@@ -335,7 +364,10 @@ struct Driver {
             std::cerr << "LENGTH_CUTOFF = " << length_cutoff << std::endl;
             std::cerr << "COVERAGE_CUTOFF = " << left_min << std::endl;
         }
-        g.delete_erroneous_iterative(length_cutoff, left_min, opt.verbose);
+        {
+            Tick t("node cleaning (host)");
+            g.delete_erroneous_iterative(length_cutoff, left_min, opt.verbose);
+        }
         avg_cov = avg_cov * (avg_len - kk + 1.0) / avg_len;
         if (atoi(opt.bubble.c_str()) > 0) {                     // assemble.cpp:520-526 (Q1: only -u >= 1 gets here)
             if (opt.verbose) std::cerr << "AVE_KMER_COV_REMOVING_BUBBLE=" << avg_cov << std::endl;
@@ -346,12 +378,16 @@ struct Driver {
         chk(pb_reads_restore(ctx));
         save_graph<W>(kk, kk);
         contig_table<W>(kk, 1.0);
-        g.delete_all();
+        {
+            Tick t("graph reset (host)");
+            g.delete_all();
+        }
         if (opt.verbose) std::cerr << "K = " << kk << ", loading kmers from contigs..." << std::endl;
         if (opt.verbose) std::cerr << "K = " << kk << ", saving additional kmers(not found in contigs) from reads..." << std::endl;
         u64 nd = 0;
         chk(pb_count_considering_contigs(ctx, kk, occ_hist.data(), &max_occ, &nd));
         retain_and_build<W>(kk, cutoff[num_k - 1]);
+        Tick t("contig records (host)");
         g.save_contig_simple(contigs, avg_len / (avg_len - kk + 1.0));
         g.save_junction(junctions, avg_len / (avg_len - kk + 1.0));
     }
@@ -372,6 +408,7 @@ template <typename F> void dispatch_w(unsigned k, F &&f)
 int run_assemble_gpu(const GpuAssembleOptions &opt)
 {
     if (opt.repeat) throw std::runtime_error("-repeat is outside the scope of the device path (DESIGN.md section 1)");
+    const auto t_start = std::chrono::steady_clock::now();
     Driver d(opt);
     d.min_log_p_join = log(1.0 - pow(10.0, -opt.safety));
     double bubble = atof(opt.bubble.c_str());
@@ -381,7 +418,6 @@ int run_assemble_gpu(const GpuAssembleOptions &opt)
     std::get<3>(d.graphs).set_thresholds(bubble, opt.branch);
     std::get<4>(d.graphs).set_thresholds(bubble, opt.branch);
 
-    const auto t_start = std::chrono::steady_clock::now();
     // the input files are parsed concurrently (one host thread per file, at most 8 at a time) and handed to the device in
     // the order of the command line, which is the order of the reference's temp file 0 at -t 1
     const size_t nf = opt.files.size();
@@ -399,6 +435,10 @@ int run_assemble_gpu(const GpuAssembleOptions &opt)
             for (size_t i = base; i < hi_f; ++i)
                 th.emplace_back([&, i]() { try { read_file(opt.files[i], fpieces[i], per_file); } catch (const std::exception &e) { ferr[i] = e.what(); if (ferr[i].empty()) ferr[i] = "read error"; } });
             for (auto &t2 : th) t2.join();
+        }
+        {
+            Tick t("wait for the device context");
+            d.ready();
         }
         {
             Tick t("device allocation for the read stream");
@@ -421,12 +461,15 @@ int run_assemble_gpu(const GpuAssembleOptions &opt)
                     lo = hi;
                 }
             }
-            // returning ~0.5 GB per file to the kernel costs ~0.15 ms per MB: done by a helper thread, off the critical path
+            // Returning ~0.5 GB per file to the kernel costs ~0.15 ms per MB: done by a helper thread.  (HIP calls made meanwhile are
+            // slowed down -- upload + first count 0.09 s instead of 0.055 s -- but leaving the buffers to the process exit costs the
+            // same time there, serially; measured both ways)
             auto *dead = new std::vector<ParsedPiece>();
             dead->swap(fpieces[i]);
             reapers.emplace_back([dead]() { delete dead; });
         }
     }
+    d.ready();
     d.k.assign(1, opt.k0);
     dispatch_w(opt.k0, [&](auto w) { d.template initial<decltype(w)::value>(); });
     if (opt.kmer_occ_only) {
@@ -455,6 +498,11 @@ int run_assemble_gpu(const GpuAssembleOptions &opt)
         std::cerr << "\n#### STAGE WALL TIMES (s) ####" << std::endl;
         for (const std::string &n : g_clock.order) std::cerr << n << "\t" << g_clock.acc[n] << std::endl;
         std::cerr << "total\t" << std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() << std::endl;
+        std::cerr << "(device context creation, beside the parse\t" << d.create_s << ")" << std::endl;
+        auto epoch = [](std::chrono::system_clock::time_point t) { return std::chrono::duration<double>(t.time_since_epoch()).count(); };
+        std::cerr.precision(16);
+        std::cerr << "(epoch at entry\t" << epoch(std::chrono::system_clock::now()) - std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count()
+                  << ")\n(epoch at return\t" << epoch(std::chrono::system_clock::now()) << ")" << std::endl;
     }
     return 0;
 }

@@ -14,6 +14,8 @@
 #include "kmer.hpp"
 #include <sstream>
 #include <algorithm>
+#include <array>
+#include <cstring>
 #include <cstdio>
 #include <iostream>
 #include <stdexcept>
@@ -42,6 +44,24 @@ struct Straight {
         seq[pos / 32] = (seq[pos / 32] & ~(3ull << ((pos % 32) * 2))) | ((u64)v << ((pos % 32) * 2));
     }
     void resize(unsigned k) { seq.resize((length + k + 30) / 32); }
+    // bases n-1 .. 0 (left to right) appended to str: four bases per table look-up instead of one get() per base
+    void append_bases(std::vector<unsigned char> &str, u64 n) const
+    {
+        static const std::array<uint32_t, 256> lut = [] {
+            std::array<uint32_t, 256> t{};
+            for (unsigned b = 0; b < 256; ++b) t[b] = ((b >> 6) & 3u) | (((b >> 4) & 3u) << 8) | (((b >> 2) & 3u) << 16) | ((b & 3u) << 24);
+            return t;
+        }();
+        const size_t at = str.size();
+        str.resize(at + n);
+        unsigned char *o = str.data() + at;
+        u64 j = 0;
+        for (; j + 4 <= n; j += 4) {                       // bases j .. j+3 land at o[n-4-j .. n-1-j], highest first
+            const uint32_t v = lut[(seq[j >> 5] >> ((j & 31) * 2)) & 0xff];
+            std::memcpy(o + (n - 4 - j), &v, 4);
+        }
+        for (; j < n; ++j) o[n - 1 - j] = (unsigned char)get(j);
+    }
 };
 struct Junction {                 // graph.h:99-106
     u16 coverage = 0;
@@ -740,7 +760,7 @@ struct Graph {
                     str.push_back(jk.get(k - 1));
                 }
             }
-            for (u64 i = 0; i < st->length + k - 1; ++i) str.push_back(st->get(st->length + k - 2 - i));
+            st->append_bases(str, st->length + k - 1);
             if (st->out & 0xf) {
                 K jk;
                 for (unsigned i = 1; i < k; ++i) jk.set(i, st->get(i - 1));
