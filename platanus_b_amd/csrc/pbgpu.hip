@@ -116,6 +116,8 @@ struct pb_ctx {
     int rel_next = 0;
     int bounce_next = 0;
     CopyPool *copy_pool = nullptr;
+    u64 *h_hist = nullptr;              // pinned; filled behind sk_bucket_kernel so that the pass needs one host synchronisation
+    bool h_hist_valid = false;
     u64 exp_cur[64] = {0};           // start of every owner's segment in the export (pb_export_begin -> pb_export_copy)
     u64 sk_records = 0;            // super-k-mer records of the last counting pass (0 = other path)
     u64 sk_flagged = 0, sk_spilled = 0, sk_extra_for = 0;
@@ -282,6 +284,7 @@ void pb_destroy(pb_ctx *ctx)
     release(ctx->layout_work); release(ctx->layout_slots); release(ctx->layout_out); release(ctx->scan_sums); release(ctx->slot_blk);
     for (auto &s : ctx->scratch) release(s);
     delete ctx->copy_pool;
+    if (ctx->h_hist) (void)hipHostFree(ctx->h_hist);
     for (int b = 0; b < 2; ++b) if (ctx->bounce[b]) { (void)hipHostFree(ctx->bounce[b]); (void)hipEventDestroy(ctx->bounce_ev[b]); }
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
@@ -463,9 +466,15 @@ static int finish_count(pb_ctx *ctx, uint64_t *occ_hist, uint64_t *max_occ)
         HIPCHK(hipGetLastError());
         if ((rc = tm.stop()) != PB_OK) return rc;
     }
-    std::vector<u64> h(65536);
-    HIPCHK(hipMemcpyAsync(h.data(), ctx->d_hist.p, 65536 * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    std::vector<u64> hv;
+    const u64 *h = ctx->h_hist;
+    if (!(ctx->h_hist_valid && done == ctx->n_distinct && done > 0)) {      // (the super-k-mer pass copied it out with its scalars)
+        hv.resize(65536);
+        HIPCHK(hipMemcpyAsync(hv.data(), ctx->d_hist.p, 65536 * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        h = hv.data();
+    }
+    ctx->h_hist_valid = false;
     if (occ_hist) for (int i = 0; i < PB_OCC_BINS; ++i) occ_hist[i] = h[i];
     if (max_occ) { *max_occ = 0; for (int i = PB_COUNT_MAX; i > 0; --i) if (h[i]) { *max_occ = (u64)i; break; } }
     return PB_OK;
@@ -623,6 +632,8 @@ static int count_superk(pb_ctx *ctx, unsigned k, bool *done)
             t3.stop();
             HIPCHK(hipGetLastError());
             HIPCHK(hipMemcpyAsync(sc, ctx->d_scalars.p, 72, hipMemcpyDeviceToHost, ctx->stream));
+            if (!ctx->h_hist) HIPCHK(hipHostMalloc((void **)&ctx->h_hist, 65536 * 8, hipHostMallocDefault));
+            HIPCHK(hipMemcpyAsync(ctx->h_hist, ctx->d_hist.p, 65536 * 8, hipMemcpyDeviceToHost, ctx->stream));   // final unless buckets were flagged
             HIPCHK(hipStreamSynchronize(ctx->stream));
             t1.read(); t2.read(); t3.read(); ti.read();
         }
@@ -636,7 +647,8 @@ static int count_superk(pb_ctx *ctx, unsigned k, bool *done)
         }
         if (!forced_b && sc[7] > nb2 / 4) return PB_OK;            // still mostly overflowing at 2^18 buckets: the direct path takes it
         ctx->stage_ms["seg_compact"] = 0.f;
-        if (sc[7] + sc[8] > 0) {
+        const bool all_in_lds = sc[7] + sc[8] == 0;                // then h_hist already holds the whole histogram
+        if (!all_in_lds) {
             StageTimer t4(ctx, "seg_compact");                     // (stage name kept for bench.py: flagged buckets through the global table)
             sk_flagged_kernel<<<dim3(grid_for(nb2, 1, 1024), 16), 256, 0, ctx->stream>>>(p);
             HIPCHK(hipGetLastError());
@@ -647,6 +659,7 @@ static int count_superk(pb_ctx *ctx, unsigned k, bool *done)
             ctx->n_instances = sc[0];
             ctx->n_distinct = sc[4];
             ctx->hist_done = sc[4];                 // sk_bucket_kernel tallied its records while it wrote them
+            ctx->h_hist_valid = all_in_lds;
             ctx->sk_records = sc[6];
             ctx->sk_bits = B;
             ctx->sk_flagged = sc[7];
