@@ -44,6 +44,18 @@ struct Straight {
         seq[pos / 32] = (seq[pos / 32] & ~(3ull << ((pos % 32) * 2))) | ((u64)v << ((pos % 32) * 2));
     }
     void resize(unsigned k) { seq.resize((length + k + 30) / 32); }
+    // this[at + p] = src[p] for p in [0, n): word-wise (the target positions must still be zero, bits of src above n are ignored)
+    void put_bases(u64 at, const std::vector<u64> &src, u64 n)
+    {
+        const u64 ws = at / 32, bs = (at % 32) * 2, nw = (n + 31) / 32;
+        for (u64 i = 0; i < nw; ++i) {
+            u64 v = i < src.size() ? src[i] : 0;
+            if (i == nw - 1 && (n % 32)) v &= ~0ull >> (64 - 2 * (n % 32));
+            if (v == 0) continue;
+            seq[ws + i] |= v << bs;
+            if (bs && ws + i + 1 < seq.size()) seq[ws + i + 1] |= v >> (64 - bs);
+        }
+    }
     // bases n-1 .. 0 (left to right) appended to str: four bases per table look-up instead of one get() per base
     void append_bases(std::vector<unsigned char> &str, u64 n) const
     {
@@ -368,8 +380,8 @@ struct Graph {
         n.coverage = static_cast<double>(l->coverage * l->length + r->coverage * r->length) / static_cast<double>(n.length) + 0.5;
         n.out = (l->out & 0xf0) | (r->out & 0x0f);
         n.resize(k);
-        for (u64 i = 0; i < l->length + k - 1; ++i) n.set(n.length + k - 2 - i, l->get(l->length + k - 2 - i));
-        for (u64 i = 0; i < r->length; ++i) n.set(r->length - 1 - i, r->get(r->length - 1 - i));
+        n.put_bases(r->length, l->seq, l->length + k - 1);          // n[r.length + p] = l[p]
+        n.put_bases(0, r->seq, r->length);                          // n[q] = r[q], q < r.length
         delete_straight(*l);
         delete_straight(*r);
         insert_straight(n);
@@ -385,7 +397,7 @@ struct Graph {
         n.out = (s->out & 0xf0) | (j.out & 0x0f);
         n.resize(k);
         n.set(0, jkey.get(0));
-        for (u64 i = 0; i < s->length + k - 1; ++i) n.set(i + 1, s->get(i));
+        n.put_bases(1, s->seq, s->length + k - 1);
         delete_straight(*s);
         delete_junction(jkey);
         insert_straight(n);
