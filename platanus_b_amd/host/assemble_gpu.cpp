@@ -466,7 +466,16 @@ int run_assemble_gpu(const GpuAssembleOptions &opt)
             // same time there, serially; measured both ways)
             auto *dead = new std::vector<ParsedPiece>();
             dead->swap(fpieces[i]);
-            reapers.emplace_back([dead]() { delete dead; });
+            reapers.emplace_back([dead]() {
+                // the pages go back 2 MB at a time (madvise holds the address-space lock shared and briefly); the munmap inside
+                // free() then finds nothing left to unmap page by page and no longer blocks the HIP calls of the main thread
+                for (ParsedPiece &pc : *dead) {
+                    const uintptr_t lo = ((uintptr_t)pc.bases.data() + 4095) & ~(uintptr_t)4095;
+                    const uintptr_t hi = ((uintptr_t)pc.bases.data() + pc.bases.capacity()) & ~(uintptr_t)4095;
+                    for (uintptr_t a = lo; a < hi; a += (2u << 20)) madvise((void *)a, std::min<uintptr_t>(2u << 20, hi - a), MADV_DONTNEED);
+                }
+                delete dead;
+            });
         }
     }
     d.ready();
