@@ -195,3 +195,12 @@ def test_cli_random_differential_against_oracle_cli():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_cli.py"), "10", "21"], capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
     assert "10 cases, 0 mismatches" in p.stdout
+
+
+def test_cli_kmer_divide_and_merge_random_options_against_oracle_cli():
+    """tools/fuzz_cli2.py: contigs and k-mer occurrence table of random heterozygous read sets through `kmer_divide` (default / -mask /
+    -r / -R) and `merge` (random -k / -l / -u): every output file of the GPU CLI byte-identical to the oracle CLI's."""
+    import sys
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_cli2.py"), "4", "11"], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+    assert "4 cases, 0 mismatches" in p.stdout

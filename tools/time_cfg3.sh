@@ -5,7 +5,7 @@ D=$(mktemp -d /tmp/cfg3_XXXX)
 python3 -c "
 import sys; sys.path.insert(0,'.')
 from platanus_b_amd import synth
-synth.write_pair_files('$D/in', 5_000_000, 100, 1)
+synth.write_pair_files('$D/in', ${1:-5000000}, ${2:-100}, 1)
 "
 for i in 1 2 3; do
   t0=$(date +%s.%N)
