@@ -3,6 +3,7 @@
 // (SURVEY section 4).  Temp files of the reference become in-memory vectors kept in file order.
 #pragma once
 #include "dhash.hpp"
+#include "../../platanus_b_amd/host/errors.hpp"
 #include <algorithm>
 #include <cstdio>
 #include <string>
@@ -143,10 +144,10 @@ struct Counter {
     // counter.h:220-238
     static double dist_average(const std::vector<u64> &d, u64 start, u64 end)
     {
-        if (end > d.size() || start > end) throw std::runtime_error("kmer distribution error");
+        if (end > d.size() || start > end) throw pbh::kmer_dist_error();       // counter.h:226
         u64 sum = 0, num = 0;
         for (u64 i = start; i <= end; ++i) { sum += i * d[i]; num += d[i]; }
-        if (num == 0) throw std::runtime_error("kmer distribution error");
+        if (num == 0) throw pbh::kmer_dist_error();                            // counter.h:236
         return (double)sum / num;
     }
     double occ_average(u64 s, u64 e) const { return dist_average(occ_hist, s, e); }

@@ -154,6 +154,9 @@ int main(int argc, char **argv)
         ReadSet reads;
         for (const std::string &f : o.files) read_fastx(f, reads);
         return run_assemble(o, reads);
+    } catch (const pbh::RefError &e) {           // main.cpp:118-127: message, exit status = error id
+        std::cerr << e.what() << std::endl;
+        return e.id;
     } catch (const std::exception &e) {
         std::cerr << "Error: " << e.what() << std::endl;
         return 2;

@@ -233,7 +233,7 @@ struct Driver {
             chk(pb_kmer_occ_fetch(ctx, slots.data(), keys.data(), counts.data()));
             Tick t("kmer_occ write");
             FILE *f = fopen((opt.out_prefix + "_kmer_occ.bin").c_str(), "wb");
-            if (!f) throw std::runtime_error("cannot open " + opt.out_prefix + "_kmer_occ.bin");
+            if (!f) throw file_error(opt.out_prefix + "_kmer_occ.bin");          // counter.h:958
             const u64 kk = k[0], nm = tsize - 1;
             fwrite(&kk, 8, 1, f);
             fwrite(&nm, 8, 1, f);
@@ -280,7 +280,7 @@ struct Driver {
             slot_of[h] = (uint32_t)(i + 1);
         }
         FILE *f = fopen((opt.out_prefix + "_kmer_occ.bin").c_str(), "wb");
-        if (!f) throw std::runtime_error("cannot open " + opt.out_prefix + "_kmer_occ.bin");
+        if (!f) throw file_error(opt.out_prefix + "_kmer_occ.bin");
         const u64 kk = k[0];
         fwrite(&kk, 8, 1, f);
         fwrite(&nmask, 8, 1, f);
@@ -424,7 +424,7 @@ int run_assemble_gpu(const GpuAssembleOptions &opt)
     std::vector<std::thread> reapers;
     struct JoinAll { std::vector<std::thread> &v; ~JoinAll() { for (auto &t : v) if (t.joinable()) t.join(); } } join_reapers{reapers};
     std::vector<std::vector<ParsedPiece>> fpieces(nf);
-    std::vector<std::string> ferr(nf);
+    std::vector<std::exception_ptr> ferr(nf);
     const unsigned hw = std::max(2u, std::thread::hardware_concurrency());
     for (size_t base = 0; base < nf; base += 8) {
         const size_t hi_f = std::min(nf, base + 8);
@@ -433,7 +433,7 @@ int run_assemble_gpu(const GpuAssembleOptions &opt)
             Tick t("read + parse files (host threads)");
             std::vector<std::thread> th;
             for (size_t i = base; i < hi_f; ++i)
-                th.emplace_back([&, i]() { try { read_file(opt.files[i], fpieces[i], per_file); } catch (const std::exception &e) { ferr[i] = e.what(); if (ferr[i].empty()) ferr[i] = "read error"; } });
+                th.emplace_back([&, i]() { try { read_file(opt.files[i], fpieces[i], per_file); } catch (...) { ferr[i] = std::current_exception(); } });
             for (auto &t2 : th) t2.join();
         }
         {
@@ -447,7 +447,7 @@ int run_assemble_gpu(const GpuAssembleOptions &opt)
             d.chk(pb_reads_reserve(d.ctx, tb, tr));
         }
         for (size_t i = base; i < hi_f; ++i) {
-            if (!ferr[i].empty()) throw std::runtime_error(ferr[i]);
+            if (ferr[i]) std::rethrow_exception(ferr[i]);
             Tick t("upload + pack reads (H2D + device)");
             for (ParsedPiece &pc : fpieces[i]) {
                 const std::vector<u64> &off = pc.off;

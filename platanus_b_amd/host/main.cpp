@@ -5,6 +5,7 @@
 #include "merge.hpp"
 #include <cstdlib>
 #include <cstring>
+#include "errors.hpp"
 #include <iostream>
 
 static void usage()
@@ -121,6 +122,9 @@ int main(int argc, char **argv)
     if (o.files.empty()) { usage(); return 1; }
     try {
         return pbh::run_assemble_gpu(o);
+    } catch (const pbh::RefError &e) {           // the reference's exceptions: message, exit status = error id (main.cpp:118-127)
+        std::cerr << e.what() << std::endl;
+        return e.id;
     } catch (const std::exception &e) {
         std::cerr << "Error: " << e.what() << std::endl;
         return 2;

@@ -2,10 +2,12 @@
 // pieces of a file in parallel.  Pure host code (no device calls): the oracle's test entry pbo_parse_file runs it on the CPU.
 #pragma once
 #include "kmer.hpp"
+#include "errors.hpp"
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -46,7 +48,7 @@ inline void parse_piece(const char *p, const char *end, bool fastq, bool first_p
     bases.reserve((size_t)(end - p) / 2 + 64);
     u64 read_start = 0;                         // the current read = bases[read_start, bases.size())
     auto flush = [&]() {
-        if (bases.size() - read_start >= 500000) throw std::runtime_error("Read file exception!!\nread length is too long");   // common.h:465-467
+        if (bases.size() - read_start >= 500000) throw read_too_long();   // common.h:465-467
         off.push_back(bases.size());
         read_start = bases.size();
     };
@@ -71,15 +73,36 @@ inline void parse_piece(const char *p, const char *end, bool fastq, bool first_p
     if (last_piece || bases.size() != read_start) flush();     // the file's trailing read is written even when empty
 }
 
+// BaseCommand::checkFileFormat (baseCommand.cpp:26-49) on the first lines of the (decompressed) file: line 2 may only hold "ACGTN"
+// (upper case), a FASTQ file needs '+' at the start of line 3; anything else is "not FASTA/FASTQ" (assemble.cpp:798)
+inline bool check_file_format(const char *data, size_t size, bool &fastq)
+{
+    std::string line[3];
+    const char *p = data, *end = data + size;
+    for (int i = 0; i < 3 && p < end; ++i) {
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+        line[i].assign(p, (size_t)((nl ? nl : end) - p));
+        line[i] = line[i].c_str();                                   // getlineFILE hands the line over as a C string (common.cpp:171)
+        p = nl ? nl + 1 : end;
+    }
+    const bool seq_ok = strspn(line[1].c_str(), "ACGTN") == line[1].size();
+    if (!line[0].empty() && line[0][0] == '>' && seq_ok) { fastq = false; return true; }
+    if (!line[0].empty() && line[0][0] == '@' && seq_ok && !line[2].empty() && line[2][0] == '+') { fastq = true; return true; }
+    return false;
+}
+
 inline void read_file(const std::string &path, std::vector<ParsedPiece> &pieces, unsigned max_threads)
 {
-    FILE *fp = nullptr;
+    // compression by content, as `file -bL` tells the reference (common.cpp:88-118), not by the name
+    FILE *fp = fopen(path.c_str(), "rb");
+    if (!fp) throw file_error(path);                                 // common.cpp:140-141
+    unsigned char magic[3] = {0, 0, 0};
+    const size_t got_magic = fread(magic, 1, 3, fp);
     bool piped = false;
-    const size_t L = path.size();
-    if (L > 3 && path.compare(L - 3, 3, ".gz") == 0) { fp = popen(("gzip -cd " + path).c_str(), "r"); piped = true; }
-    else if (L > 4 && path.compare(L - 4, 4, ".bz2") == 0) { fp = popen(("bzip2 -cd " + path).c_str(), "r"); piped = true; }
-    else fp = fopen(path.c_str(), "rb");
-    if (!fp) throw std::runtime_error("cannot open " + path);
+    if (got_magic >= 2 && magic[0] == 0x1f && magic[1] == 0x8b) { fclose(fp); fp = popen(("gzip -cd " + path).c_str(), "r"); piped = true; }
+    else if (got_magic == 3 && magic[0] == 'B' && magic[1] == 'Z' && magic[2] == 'h') { fclose(fp); fp = popen(("bzip2 -cd " + path).c_str(), "r"); piped = true; }
+    else rewind(fp);
+    if (!fp) throw file_error(path);
     std::string buf;
     const char *data = nullptr;
     size_t size = 0;
@@ -100,9 +123,8 @@ inline void read_file(const std::string &path, std::vector<ParsedPiece> &pieces,
     }
     if (piped) pclose(fp); else fclose(fp);
     struct Unmap { void *m; size_t n; ~Unmap() { if (m != MAP_FAILED) munmap(m, n); } } unmap{map, size};
-    if (size == 0) throw std::runtime_error("empty read file " + path);
-    const bool fastq = data[0] == '@';
-    if (!fastq && data[0] != '>') throw std::runtime_error("Read file exception!!\nRead file is not FASTA/FASTQ format.");
+    bool fastq = false;
+    if (!check_file_format(data, size, fastq)) throw read_error("Read file exception!!\nRead file is not FASTA/FASTQ format.");   // assemble.cpp:798
     // cut points: the first line at or after i * size / n that starts with the record mark
     const char mark = fastq ? '@' : '>';
     size_t piece_bytes = 8u << 20;
@@ -123,15 +145,15 @@ inline void read_file(const std::string &path, std::vector<ParsedPiece> &pieces,
     cut.push_back(size);
     const size_t np = cut.size() - 1;
     pieces.assign(np, ParsedPiece());
-    std::vector<std::string> err(np);
+    std::vector<std::exception_ptr> err(np);
     std::vector<std::thread> th;
     for (size_t i = 0; i < np; ++i)
         th.emplace_back([&, i]() {
             try { parse_piece(data + cut[i], data + cut[i + 1], fastq, i == 0, i + 1 == np, pieces[i]); }
-            catch (const std::exception &e) { err[i] = e.what(); if (err[i].empty()) err[i] = "read error"; }
+            catch (...) { err[i] = std::current_exception(); }
         });
     for (auto &t : th) t.join();
-    for (size_t i = 0; i < np; ++i) if (!err[i].empty()) throw std::runtime_error(err[i]);
+    for (size_t i = 0; i < np; ++i) if (err[i]) std::rethrow_exception(err[i]);
 }
 
 

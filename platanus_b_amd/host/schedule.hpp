@@ -4,6 +4,7 @@
 // and the oracle.
 #pragma once
 #include "kmer.hpp"
+#include "errors.hpp"
 #include <cmath>
 #include <iostream>
 #include <stdexcept>
@@ -87,10 +88,10 @@ inline u64 left_local_minimal_value(const std::vector<u64> &hist, u64 max_occ, u
 // counter.h:220-238
 inline double dist_average(const std::vector<u64> &d, u64 start, u64 end)
 {
-    if (end > d.size() || start > end) throw std::runtime_error("kmer distribution error");
+    if (end > d.size() || start > end) throw kmer_dist_error();
     u64 sum = 0, num = 0;
     for (u64 i = start; i <= end && i < d.size(); ++i) { sum += i * d[i]; num += d[i]; }
-    if (num == 0) throw std::runtime_error("kmer distribution error");
+    if (num == 0) throw kmer_dist_error();
     return (double)sum / num;
 }
 

@@ -81,11 +81,21 @@ def test_cli_usage_and_errors(tmp_path):
     assert p.returncode == 1
 
 
+def test_cli_degenerate_inputs_and_exit_status():
+    """tools/edge_cli.py: inputs without a countable k-mer, empty / unreadable / mis-formatted files, gzip data under a plain name,
+    homopolymers and palindromes: exit status (the reference's error ids, main.cpp:118-127) and files equal to the oracle CLI's and,
+    where oracle/_ref was built, the real reference's."""
+    import sys
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "edge_cli.py")], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+    assert "0 mismatches" in p.stdout
+
+
 def _write_fasta(path, codes, width=60, lower_every=7):
     with open(path, "w") as f:
         for i, r in enumerate(codes):
             s = "".join("ACGTN"[c] for c in r)
-            if i % lower_every == 0:
+            if i % lower_every == 3:          # not record 0: the second line of a file may only hold "ACGTN" (baseCommand.cpp:39-44)
                 s = s.lower()
             f.write(f">read{i}\n")
             for j in range(0, len(s), width):
@@ -93,8 +103,8 @@ def _write_fasta(path, codes, width=60, lower_every=7):
 
 
 def test_cli_fasta_multiline_lowercase_and_gzip_match_oracle_cli(tmp_path):
-    """Reader rules of assemble.cpp:790-986: multi-line FASTA records are joined, lower case is accepted (Char2Bin,
-    common.h:256), gzip input goes through `gzip -cd`.  Compared with the oracle's CLI on the same files."""
+    """Reader rules of assemble.cpp:790-986: multi-line FASTA records are joined, lower case is accepted after the format check
+    (Char2Bin, common.h:256), gzip input goes through `gzip -cd`.  Compared with the oracle's CLI on the same files."""
     from platanus_b_amd import synth
     oracle_cli = os.path.join(ROOT, "oracle", "pb_oracle")
     assert os.path.exists(oracle_cli)

@@ -1,0 +1,77 @@
+"""Development aid: degenerate inputs through the GPU CLI, the oracle CLI and (when it was built) the real reference: exit codes and
+output files must agree.  usage: python tools/edge_cli.py"""
+import filecmp
+import os
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GPU = os.path.join(ROOT, "platanus_b_amd", "bin", "platanus_b")
+ORC = os.path.join(ROOT, "oracle", "pb_oracle")
+REF = os.path.join(ROOT, "oracle", "_ref", "platanus_b")
+
+
+def fq(reads):
+    return "".join(f"@r{i}\n{r}\n+\n{'I' * len(r)}\n" for i, r in enumerate(reads))
+
+
+CASES = {
+    "reads_shorter_than_k": fq(["ACGTACGTAC", "TTGCA", "GGGGCCCCAAAATTTT"]),
+    "single_read": fq(["ACGTTGCAAGGCTTAACCGGTTAAGGCCTTAGCAGCATCGACTAGCTAGCATCAGCTACGACTACGACTAGCATCGACTACGATCAGCACTAGC"]),
+    "only_n": fq(["N" * 100, "N" * 150]),
+    "empty_read_between": "@a\n\n+\n\n" + fq(["ACGTTGCAAGGCTTAACCGGTTAAGGCCTTAGCAGCATCGACTAGCTAGCATCAGC"] * 6),
+    "identical_reads": fq(["ACGTTGCAAGGCTTAACCGGTTAAGGCCTTAGCAGCATCGACTAGCTAGCATCAGCTACGACTACGACTAGCATCGACTACGATCAGCACTAGC"] * 40),
+    "homopolymer": fq(["A" * 150] * 30 + ["T" * 150] * 30),
+    "palindromes": fq(["ACGTACGTACGTACGTACGTACGTACGTACGTACGTACGTACGTACGTACGT" * 2] * 25 + ["GAATTCGAATTCGAATTCGAATTCGAATTCGAATTCGAATTCGAATTC" * 2] * 25),
+    "empty_file": "",
+    "lower_case_second_line": fq(["acgttgcaaggcttaaccggttaaggccttagcagcatcgactagctagcatcagc"] * 6),
+    "not_a_read_file": "hello\nworld\n",
+    "fastq_without_plus": "@r0\nACGT\nIIII\n",
+    "fasta_lower_case_later": ">a\nACGTTGCAAGGCTTAACCGGTTAAGGCCTTAGCAGCATCGACTAGCTAGCATCAGC\n" + ">b\nacgttgcaaggcttaaccggttaaggccttagcagcatcgactagctagcatcagc\n" * 5,
+    "missing_file": None,
+    "gzip_under_plain_name": b"gz",
+}
+READS = fq(["ACGTTGCAAGGCTTAACCGGTTAAGGCCTTAGCAGCATCGACTAGCTAGCATCAGCTACGACTACGACTAGCATCGACTACGATCAGCACTAGC"] * 20)
+
+
+def main():
+    bins = [("gpu", GPU), ("oracle", ORC)] + ([("reference", REF)] if os.path.exists(REF) else [])
+    bad = 0
+    for name, text in CASES.items():
+        with tempfile.TemporaryDirectory() as td:
+            if text == b"gz":
+                import gzip
+                with gzip.open(os.path.join(td, "in.fq"), "wt") as f:
+                    f.write(READS)
+            elif text is not None:
+                open(os.path.join(td, "in.fq"), "w").write(text)
+            res = {}
+            for who, b in bins:
+                d = os.path.join(td, who)
+                os.mkdir(d)
+                p = subprocess.run([b, "assemble", "-k", "21", "-t", "1", "-m", "1", "-o", "out", "-f", "../in.fq"], cwd=d, capture_output=True, text=True, timeout=300)
+                res[who] = (p.returncode, d, p.stderr[-300:])
+            base = res["reference"] if "reference" in res else res["oracle"]
+            line = [f"{who}: rc {res[who][0]} files {sorted(os.listdir(res[who][1]))}" for who, _ in bins]
+            ok = True
+            for who, _ in bins:
+                if res[who][0] != base[0]:
+                    ok = False
+                if res[who][0] == 0 and base[0] == 0:
+                    for fn in os.listdir(base[1]):
+                        f2 = os.path.join(res[who][1], fn)
+                        if not os.path.exists(f2) or not filecmp.cmp(os.path.join(base[1], fn), f2, shallow=False):
+                            ok = False
+                            line.append(f"{who}: {fn} differs")
+            bad += not ok
+            print(("ok       " if ok else "MISMATCH ") + name + " | " + " | ".join(line), flush=True)
+            if not ok:
+                for who, _ in bins:
+                    print(f"    {who} stderr tail: {res[who][2]!r}")
+    print(f"{len(CASES)} cases, {bad} mismatches")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
