@@ -625,7 +625,8 @@ static int count_superk(pb_ctx *ctx, unsigned k, bool *done)
             // a few blocks per sub-stream, each striding over its tiles (most of cap1 is head-room: one block per tile would be mostly empty blocks)
             const u64 exp_tiles = (u64)(est_rec / (double)nb1) / SK2_RCAP + 1;
             const unsigned blocks_per_sub = (unsigned)std::min<u64>(std::max<u64>(exp_tiles / 4, 1), 64);
-            sk_part2_kernel<SkStore12><<<dim3(blocks_per_sub, (unsigned)nb1), SK_THREADS, 0, ctx->stream>>>(p);
+            if (getenv("PB_PART2_GENERIC")) sk_part2_kernel<SkStore12><<<dim3(blocks_per_sub, (unsigned)nb1), SK_THREADS, 0, ctx->stream>>>(p);   // development / A-B
+            else sk_part2_raw12_kernel<<<dim3(blocks_per_sub, (unsigned)nb1), SK_THREADS, 0, ctx->stream>>>(p);
             t2.stop();
             LazyTimer t3(ctx, "bucket", 2);
             sk_bucket_kernel<<<grid_for(nb2, 1, 256 * 16), SK_ROLL_THREADS, 0, ctx->stream>>>(p, (u64 *)ctx->dist_keys.p, (u32 *)ctx->dist_counts.p, out_cap);
