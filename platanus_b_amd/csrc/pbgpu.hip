@@ -918,7 +918,9 @@ static int merge_records_lds(pb_ctx *ctx, const void *dev_keys, const void *dev_
     p.cursor2 = p.cursor1 + nb1;
     p.flag2 = p.cursor2 + nb2;
     p.fallback = TableView<1>{nullptr, 0};
-    p.hist = nullptr;
+    if ((rc = ensure(ctx, ctx->d_hist, 65536 * 8)) != PB_OK) return rc;
+    p.hist = (u64 *)ctx->d_hist.p;
+    HIPCHK(hipMemsetAsync(ctx->d_hist.p, 0, 65536 * 8, ctx->stream));
     p.scalars = (u64 *)ctx->d_scalars.p;
     if ((rc = ensure(ctx, ctx->dist_keys, n * 8)) != PB_OK) return rc;
     if ((rc = ensure(ctx, ctx->dist_counts, n * 4)) != PB_OK) return rc;
@@ -935,6 +937,7 @@ static int merge_records_lds(pb_ctx *ctx, const void *dev_keys, const void *dev_
     if ((rc = tm.stop()) != PB_OK) return rc;
     if (sc[1] || sc[7] || sc[8]) return PB_OK;              // a region or a table overflowed (one key with a huge share): the table path takes it
     ctx->n_distinct = sc[4];
+    ctx->hist_done = sc[4];                  // mg_bucket_kernel tallied every record it wrote
     ctx->n_retained = 0;
     *done = true;
     return PB_OK;

@@ -64,14 +64,17 @@ def exchange_and_merge(g, dist, world: int, rank: int):
     mx, nd = C.c_uint64(), C.c_uint64()
     g._chk(lib.pb_merge_records(h, g.k, C.c_void_p(rk.data_ptr()), C.c_void_p(rcnt.data_ptr()), total, hist.ctypes.data, C.byref(mx), C.byref(nd)))
     red_dev = torch.device("cpu") if dist.get_backend() == "gloo" else dev
-    th = torch.from_numpy(hist.astype(np.int64)).to(red_dev)
+    # one all_reduce for the histogram and the distinct count (one more bin at the end)
+    both = np.empty(PB_OCC_BINS + 1, dtype=np.int64)
+    both[:PB_OCC_BINS] = hist.astype(np.int64)
+    both[PB_OCC_BINS] = nd.value
+    th = torch.from_numpy(both).to(red_dev)
     dist.all_reduce(th)
-    ghist = th.cpu().numpy().astype(np.uint64)
+    tot = th.cpu().numpy()
+    ghist = tot[:PB_OCC_BINS].astype(np.uint64)
     g.occ_hist = ghist
     nz = np.nonzero(ghist[1:65535])[0]
     g.max_occ = int(nz[-1]) + 1 if nz.size else 0
-    tn = torch.tensor([nd.value], dtype=torch.int64, device=red_dev)
-    dist.all_reduce(tn)
     g.n_distinct_local = nd.value
-    g.n_distinct = int(tn.item())
+    g.n_distinct = int(tot[PB_OCC_BINS])
     return ghist
