@@ -28,6 +28,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # this pool's driver only supports dmabuf IPC (RCCL across processes needs it)
 
 GENOME = 5_000_000
 COVERAGE = 100.0
