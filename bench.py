@@ -177,7 +177,7 @@ def main():
         achieved = instances * BYTES_PER_INSTANCE / (k_ms * 1e-3) / 1e9
         parts = {st: float(np.mean(v)) for st, v in stage_ms.items()}
         partitioned = parts["part1"] > 0
-        kernel = ("sk_part1_kernel + sk_part2_kernel + sk_bucket_kernel + sk_flagged_kernel (super-k-mer counting pass)"
+        kernel = ("sk_part1_kernel + sk_part2_raw12_kernel + sk_bucket_kernel + sk_flagged_kernel (super-k-mer counting pass)"
                   if partitioned else "count_kernel<1> (direct global-atomic counting pass)")
         # HBM bytes per counting pass from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes
         # of this same command, corrected as MI355X_MICROARCH.md prescribes): profiles/r01_hbm_traffic.json.  Only quoted
