@@ -94,6 +94,14 @@ int pb_fetch_all(pb_ctx *ctx, uint64_t *keys, uint32_t *counts, uint64_t cap, ui
  *                    the caller all-reduces the histograms (sum) to get the global occurrenceDistribution. */
 int pb_export_begin(pb_ctx *ctx, int n_parts, uint64_t *part_counts);
 int pb_export_copy(pb_ctx *ctx, void *dev_keys, void *dev_counts);
+/* The same export with fewer bytes for the wire: inside an owner's segment the records with count 1 (most of a sequencing-depth
+ * table: k-mers with a sequencing error, counter.h:464 "first sight = 1") come first and travel as bare keys, the others follow
+ * with a 16-bit count (clamped to 65535; the sum saturates at 65534 at read-out, counter.h:468-470).
+ *   pb_export_split_begin  single_counts[n_parts], multi_counts[n_parts]
+ *   pb_export_split_copy   dev_keys u64[(singles + multis) * W] owner by owner (singles, then multis);
+ *                          dev_counts16 u16[multis]: the multis of owner 0, of owner 1, ... */
+int pb_export_split_begin(pb_ctx *ctx, int n_parts, uint64_t *single_counts, uint64_t *multi_counts);
+int pb_export_split_copy(pb_ctx *ctx, void *dev_keys, void *dev_counts16);
 int pb_merge_begin(pb_ctx *ctx, unsigned k, uint64_t expected_records);
 int pb_merge_add(pb_ctx *ctx, const void *dev_keys, const void *dev_counts, uint64_t n);
 int pb_merge_end(pb_ctx *ctx, uint64_t *occ_hist, uint64_t *max_occ, uint64_t *n_distinct);

@@ -63,6 +63,8 @@ def load_library() -> C.CDLL:
     lib.pb_last_kernel_ms.argtypes = [vp, C.c_char_p, C.POINTER(C.c_float)]
     lib.pb_export_begin.argtypes = [vp, C.c_int, u64p]
     lib.pb_export_copy.argtypes = [vp, vp, vp]
+    lib.pb_export_split_begin.argtypes = [vp, C.c_int, u64p, u64p]
+    lib.pb_export_split_copy.argtypes = [vp, vp, vp]
     lib.pb_merge_begin.argtypes = [vp, C.c_uint, C.c_uint64]
     lib.pb_merge_add.argtypes = [vp, vp, vp, C.c_uint64]
     lib.pb_merge_end.argtypes = [vp, vp, u64p, u64p]

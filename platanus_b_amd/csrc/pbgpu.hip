@@ -119,6 +119,8 @@ struct pb_ctx {
     u64 *h_hist = nullptr;              // pinned; filled behind sk_bucket_kernel so that the pass needs one host synchronisation
     bool h_hist_valid = false;
     u64 exp_cur[64] = {0};           // start of every owner's segment in the export (pb_export_begin -> pb_export_copy)
+    u64 exp2_key_start[128] = {0}, exp2_cnt_start[64] = {0};   // pb_export_split_begin -> pb_export_split_copy
+    unsigned exp2_parts = 0;
     u64 sk_records = 0;            // super-k-mer records of the last counting pass (0 = other path)
     u64 sk_flagged = 0, sk_spilled = 0, sk_extra_for = 0;
     u64 hist_done = 0;              // leading records of the distinct arrays already tallied into d_hist
@@ -831,6 +833,61 @@ int pb_export_begin(pb_ctx *ctx, int n_parts, uint64_t *part_counts)
     for (int i = 0; i < n_parts; ++i) ctx->exp_cur[i] = cur[i];
     HIPCHK(hipGetLastError());
     return tm.stop();
+}
+
+// Split export (see part_count2_kernel): per owner the number of count-1 records and of the others
+int pb_export_split_begin(pb_ctx *ctx, int n_parts, uint64_t *single_counts, uint64_t *multi_counts)
+{
+    if (!ctx || !single_counts || !multi_counts || n_parts < 1 || n_parts > PB_MAX_PARTS || ctx->W == 0) return PB_EINVAL;
+    (void)hipSetDevice(ctx->dev);
+    int rc;
+    const u64 nd = ctx->n_distinct;
+    DevBuf &pc = ctx->scratch[0];
+    // dest counts [128] | cursors [128] | key_start [128] | cnt_start [64]
+    if ((rc = ensure(ctx, pc, (3 * 2 * PB_MAX_PARTS + PB_MAX_PARTS) * 8)) != PB_OK) return rc;
+    HIPCHK(hipMemsetAsync(pc.p, 0, 2 * PB_MAX_PARTS * 8, ctx->stream));
+    StageTimer tm(ctx, "export");
+    if (nd)
+        part_count2_kernel<<<grid_for(nd, 256, 256 * 8), 256, 0, ctx->stream>>>((const u64 *)ctx->dist_keys.p, (const u32 *)ctx->dist_counts.p, nd, ctx->W,
+                                                                                (unsigned)n_parts, (u64 *)pc.p);
+    u64 h[2 * PB_MAX_PARTS];
+    HIPCHK(hipMemcpyAsync(h, pc.p, 2 * n_parts * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    u64 kpos = 0, cpos = 0;
+    for (int o = 0; o < n_parts; ++o) {
+        single_counts[o] = h[2 * o];
+        multi_counts[o] = h[2 * o + 1];
+        ctx->exp2_key_start[2 * o] = kpos;
+        ctx->exp2_key_start[2 * o + 1] = kpos + h[2 * o];
+        ctx->exp2_cnt_start[o] = cpos;
+        kpos += h[2 * o] + h[2 * o + 1];
+        cpos += h[2 * o + 1];
+    }
+    ctx->exp_total = kpos;
+    ctx->exp2_parts = (unsigned)n_parts;
+    HIPCHK(hipGetLastError());
+    return tm.stop();
+}
+
+// dev_keys: room for every exported record (sum of both classes, W words each); dev_counts16: one u16 per record with count > 1
+int pb_export_split_copy(pb_ctx *ctx, void *dev_keys, void *dev_counts16)
+{
+    if (!ctx || ctx->exp2_parts == 0) return PB_EINVAL;
+    (void)hipSetDevice(ctx->dev);
+    const u64 nd = ctx->n_distinct;
+    if (ctx->exp_total && nd) {
+        u64 *base = (u64 *)ctx->scratch[0].p;
+        u64 *cursors = base + 2 * PB_MAX_PARTS, *key_start = cursors + 2 * PB_MAX_PARTS, *cnt_start = key_start + 2 * PB_MAX_PARTS;
+        HIPCHK(hipMemcpyAsync(cursors, ctx->exp2_key_start, 2 * ctx->exp2_parts * 8, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(key_start, ctx->exp2_key_start, 2 * ctx->exp2_parts * 8, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(cnt_start, ctx->exp2_cnt_start, ctx->exp2_parts * 8, hipMemcpyHostToDevice, ctx->stream));
+        part_scatter2_kernel<<<grid_for(nd, 256 * PSC_RPT, 256 * 8), 256, 0, ctx->stream>>>((const u64 *)ctx->dist_keys.p, (const u32 *)ctx->dist_counts.p, nd, ctx->W,
+                                                                                          ctx->exp2_parts, cursors, key_start, cnt_start, (u64 *)dev_keys,
+                                                                                          (unsigned short *)dev_counts16);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return PB_OK;
 }
 
 // the records are scattered straight into the caller's buffers (no staging copy)

@@ -13,6 +13,7 @@ that is how tests/test_multigpu_gloo.py covers the N>1 path without a GPU.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -41,6 +42,37 @@ def exchange_records(dist, torch, keys, counts, send_counts, W: int):
     return rk, rcnt, recv
 
 
+def exchange_records_split(dist, torch, keys, counts16, n_single, n_multi, W: int):
+    """The same exchange with 9 instead of 12 bytes per record: inside every owner's segment of `keys` (int64 [.. * W]) the records
+    with count 1 come first and have no count at all, the others have a 16-bit count in `counts16` (uint8 [2 * sum(n_multi)], the
+    little-endian u16 counts of owner 0's multis, owner 1's, ...; NCCL has no 16-bit integer type, so bytes travel).
+    Returns (recv_keys, recv_counts int32 with the ones filled in, records received per rank)."""
+    world = dist.get_world_size()
+    dev = keys.device
+    if dev.type == "cuda" and dist.get_backend() == "gloo":
+        rk, rcnt, recv = exchange_records_split(dist, torch, keys.cpu(), counts16.cpu(), n_single, n_multi, W)
+        return rk.to(dev), rcnt.to(dev), recv
+    sc = torch.tensor([v for o in range(world) for v in (int(n_single[o]), int(n_multi[o]))], dtype=torch.int64, device=dev)
+    rc = torch.empty(2 * world, dtype=torch.int64, device=dev)
+    dist.all_to_all_single(rc, sc)
+    rl = [int(x) for x in rc.tolist()]
+    rs, rm = rl[0::2], rl[1::2]
+    recv = [a + b for a, b in zip(rs, rm)]
+    rk = torch.empty(sum(recv) * W, dtype=torch.int64, device=dev)
+    dist.all_to_all_single(rk, keys, [r * W for r in recv], [(int(n_single[o]) + int(n_multi[o])) * W for o in range(world)])
+    rc8 = torch.empty(2 * sum(rm), dtype=torch.uint8, device=dev)
+    dist.all_to_all_single(rc8, counts16, [2 * m for m in rm], [2 * int(m) for m in n_multi])
+    rcnt = torch.ones(sum(recv), dtype=torch.int32, device=dev)
+    c16 = rc8.view(torch.int16)
+    off = moff = 0
+    for i in range(world):                      # source i sent rs[i] singles, then rm[i] multis
+        if rm[i]:
+            rcnt[off + rs[i]:off + recv[i]] = c16[moff:moff + rm[i]].to(torch.int32) & 0xFFFF
+        off += recv[i]
+        moff += rm[i]
+    return rk, rcnt, recv
+
+
 def exchange_and_merge(g, dist, world: int, rank: int):
     """g: GpuCounter that has just counted this rank's reads.  After the call g's table is this rank's owner
     shard of the global table and g.occ_hist / g.max_occ / g.n_distinct describe the GLOBAL distribution."""
@@ -48,16 +80,27 @@ def exchange_and_merge(g, dist, world: int, rank: int):
     from .binding import PB_OCC_BINS, words_for_k
     lib, h = g.lib, g.h
     W = words_for_k(g.k)
-    part = (C.c_uint64 * world)()
-    g._chk(lib.pb_export_begin(h, world, part))
-    send = [int(x) for x in part]
-    n = sum(send)
     dev = torch.device("cuda", torch.cuda.current_device())
-    keys = torch.empty(max(n, 1) * W, dtype=torch.int64, device=dev)
-    counts = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
-    torch.cuda.synchronize()
-    g._chk(lib.pb_export_copy(h, C.c_void_p(keys.data_ptr()), C.c_void_p(counts.data_ptr())))
-    rk, rcnt, recv = exchange_records(dist, torch, keys[:n * W], counts[:n], send, W)
+    if os.environ.get("PB_EXCHANGE") == "v1":          # development / A-B: every record with a 32-bit count
+        part = (C.c_uint64 * world)()
+        g._chk(lib.pb_export_begin(h, world, part))
+        send = [int(x) for x in part]
+        n = sum(send)
+        keys = torch.empty(max(n, 1) * W, dtype=torch.int64, device=dev)
+        counts = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        g._chk(lib.pb_export_copy(h, C.c_void_p(keys.data_ptr()), C.c_void_p(counts.data_ptr())))
+        rk, rcnt, recv = exchange_records(dist, torch, keys[:n * W], counts[:n], send, W)
+    else:
+        ns, nm = (C.c_uint64 * world)(), (C.c_uint64 * world)()
+        g._chk(lib.pb_export_split_begin(h, world, ns, nm))
+        n_single, n_multi = [int(x) for x in ns], [int(x) for x in nm]
+        n, n_m = sum(n_single) + sum(n_multi), sum(n_multi)
+        keys = torch.empty(max(n, 1) * W, dtype=torch.int64, device=dev)
+        counts16 = torch.empty(max(2 * n_m, 2), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        g._chk(lib.pb_export_split_copy(h, C.c_void_p(keys.data_ptr()), C.c_void_p(counts16.data_ptr())))
+        rk, rcnt, recv = exchange_records_split(dist, torch, keys[:n * W], counts16[:2 * n_m], n_single, n_multi, W)
     torch.cuda.synchronize()                 # the library runs on its own stream
     total = sum(recv)
     hist = np.zeros(PB_OCC_BINS, dtype=np.uint64)

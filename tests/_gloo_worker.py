@@ -12,7 +12,7 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from platanus_b_amd import synth  # noqa: E402
-from platanus_b_amd.multigpu import exchange_records, owner_of  # noqa: E402
+from platanus_b_amd.multigpu import exchange_records, exchange_records_split, owner_of  # noqa: E402
 from oracle.pyoracle import OracleCounter  # noqa: E402
 
 
@@ -32,12 +32,23 @@ def main():
     oc.count(codes.reshape(-1), np.arange(n + 1, dtype=np.uint64) * np.uint64(L), k)
     keys, counts = oc.retain(1)
     own = owner_of(keys[:, 0], world)
-    order = np.argsort(own, kind="stable")
-    keys, counts, own = keys[order], counts[order], own[order]
-    send = [int((own == r).sum()) for r in range(world)]
-    tk = torch.from_numpy(keys.reshape(-1).view(np.int64).copy())
-    tc = torch.from_numpy(counts.astype(np.int32))
-    rk, rc, recv = exchange_records(dist, torch, tk, tc, send, W)
+    mode = sys.argv[3] if len(sys.argv) > 3 else "split"
+    if mode == "v1":                                    # every record with a 32-bit count
+        order = np.argsort(own, kind="stable")
+        keys, counts, own = keys[order], counts[order], own[order]
+        send = [int((own == r).sum()) for r in range(world)]
+        tk = torch.from_numpy(keys.reshape(-1).view(np.int64).copy())
+        tc = torch.from_numpy(counts.astype(np.int32))
+        rk, rc, recv = exchange_records(dist, torch, tk, tc, send, W)
+    else:                                               # count-1 records as bare keys, the others with 16-bit counts (what pb_export_split_* lays out)
+        order = np.lexsort((counts > 1, own))           # by owner, singles before multis
+        keys, counts, own = keys[order], counts[order], own[order]
+        n_single = [int(((own == r) & (counts == 1)).sum()) for r in range(world)]
+        n_multi = [int(((own == r) & (counts > 1)).sum()) for r in range(world)]
+        tk = torch.from_numpy(keys.reshape(-1).view(np.int64).copy())
+        c16 = np.minimum(counts[counts > 1], 65535).astype("<u2")
+        tc = torch.from_numpy(c16.view(np.uint8).copy())
+        rk, rc, recv = exchange_records_split(dist, torch, tk, tc, n_single, n_multi, W)
     rkeys = rk.numpy().view(np.uint64).reshape(-1, W)
     assert (owner_of(rkeys[:, 0], world) == rank).all()
     # owner-side merge: add counts of equal keys, saturate at 65534 (counter.h:468-470)

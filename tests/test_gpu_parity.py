@@ -245,6 +245,47 @@ def test_export_buckets_and_merge_roundtrip(k, gpu, oracle_built):
     assert np.array_equal(gc, np.minimum(ocn.astype(np.int64) * 2, 65534).astype(np.uint16))
 
 
+@pytest.mark.parametrize("k", [32, 45])
+def test_split_export_layout(k, gpu, oracle_built):
+    """pb_export_split_*: 5 owners; inside every owner's key segment the count-1 records come first (no count travels for them), then
+    the others, whose 16-bit counts sit owner by owner in the count buffer.  Reassembled, the records are exactly the oracle's table."""
+    import ctypes as C
+    import torch
+    from platanus_b_amd import synth
+    from platanus_b_amd.multigpu import owner_of
+    r1, r2 = synth.make_reads(30_000, 40, seed=4, n_rate=0.001)
+    codes = np.concatenate([r1, r2])
+    n, L = codes.shape
+    oc = _oracle(codes, np.arange(n + 1, dtype=np.uint64) * np.uint64(L), k, oracle_built)
+    ok, ocn = oc.retain(1)
+    W = (k + 31) // 32
+    P = 5
+    g = gpu(0)
+    g.reads_append_matrix(codes)
+    g.make_kmer_read_distribution(k)
+    ns, nm = (C.c_uint64 * P)(), (C.c_uint64 * P)()
+    g._chk(g.lib.pb_export_split_begin(g.h, P, ns, nm))
+    ns, nm = [int(x) for x in ns], [int(x) for x in nm]
+    assert sum(ns) + sum(nm) == len(ok) and sum(ns) == int((ocn == 1).sum())
+    tk = torch.empty((sum(ns) + sum(nm)) * W, dtype=torch.int64, device="cuda")
+    tc = torch.empty(max(2 * sum(nm), 2), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    g._chk(g.lib.pb_export_split_copy(g.h, C.c_void_p(tk.data_ptr()), C.c_void_p(tc.data_ptr())))
+    keys = tk.cpu().numpy().view(np.uint64).reshape(-1, W)
+    c16 = tc.cpu().numpy()[:2 * sum(nm)].view("<u2")
+    own = owner_of(keys[:, 0], P)
+    counts = np.ones(len(keys), dtype=np.int64)
+    koff = moff = 0
+    for o in range(P):
+        assert (own[koff:koff + ns[o] + nm[o]] == o).all()
+        counts[koff + ns[o]:koff + ns[o] + nm[o]] = c16[moff:moff + nm[o]]
+        assert (c16[moff:moff + nm[o]] > 1).all()
+        koff += ns[o] + nm[o]
+        moff += nm[o]
+    order = np.lexsort(tuple(keys[:, w] for w in range(W)))       # most significant word last = primary
+    assert np.array_equal(keys[order], ok) and np.array_equal(counts[order], ocn.astype(np.int64))
+
+
 def test_exchange_and_merge_over_rccl_single_rank(gpu, oracle_built):
     """The multi-GPU step (export by owner -> all_to_all over RCCL -> owner merge -> histogram all-reduce) on a real
     device with world_size 1: every record travels through torch.distributed (backend nccl = RCCL) and must come back

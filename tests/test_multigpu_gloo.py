@@ -12,12 +12,12 @@ import pytest
 from conftest import ROOT
 
 
-@pytest.mark.parametrize("k,port", [(32, 29541), (45, 29542)])
-def test_owner_exchange_world2_matches_single_process(k, port, tmp_path, oracle_built):
+@pytest.mark.parametrize("k,port,mode", [(32, 29541, "split"), (45, 29542, "split"), (32, 29543, "v1")])
+def test_owner_exchange_world2_matches_single_process(k, port, mode, tmp_path, oracle_built):
     out = tmp_path / "res.json"
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "tests", "_gloo_worker.py"), str(k), str(out)]
+           "--master-port", str(port), os.path.join(ROOT, "tests", "_gloo_worker.py"), str(k), str(out), mode]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
     res = json.load(open(out))
