@@ -172,6 +172,20 @@ def main():
     else:
         total_instances = instances
 
+    copy_gbs = None
+    if rank == 0 and world == 1:
+        # measured ceiling beside the spec peak: device-to-device copy of 1 GiB, bytes read + written
+        a_ = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
+        b_ = torch.empty_like(a_)
+        b_.copy_(a_)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            b_.copy_(a_)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 5 * 2 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del a_, b_
     if rank == 0:
         k_ms = float(np.mean(count_ms))        # all kernels of the counting pass (HIP events on the library's stream)
         achieved = instances * BYTES_PER_INSTANCE / (k_ms * 1e-3) / 1e9
@@ -195,7 +209,7 @@ def main():
                        "reads_per_gpu": int(n_reads), "kmer_instances_per_gpu": int(instances), "distinct_kmers": int(g.n_distinct),
                        "parallelism": f"reads range-partitioned over {world} GPU(s)" + (", owner exchange over RCCL" if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": k_ms,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": k_ms, "measured_d2d_copy_GBs": copy_gbs,
                          "algorithmic_bytes_per_launch": instances * BYTES_PER_INSTANCE,
                          "kernels_ms": {"part1": parts["part1"], "part2": parts["part2"], "bucket_count": parts["bucket"],
                                         "flagged_buckets": parts["seg_compact"], "table_init": float(np.mean(init_ms)),
