@@ -96,6 +96,39 @@ def cpu_baseline(sample_cov=20.0, threads=None):
             "sample": f"{GENOME / 1e6:g} Mbp x {sample_cov / 4:.0f}x PE{READ_LEN} seed {SEED}, oracle/ restatement -t 1, {dt:.1f} s"}
 
 
+def end_to_end():
+    """BASELINE.json's second metric: wall time of the drop-in CLI on the bench workload (FASTQ files in, files out, process start to
+    exit): `assemble -kmer_occ_only` (configs[1]) and the full multi-k `assemble` (configs[2]); the outputs of the latter are compared
+    with the md5 of the real reference's files for this input (tests/golden/manifest.json, cfg3)."""
+    import hashlib
+    from platanus_b_amd import synth
+    cli = os.path.join(ROOT, "platanus_b_amd", "bin", "platanus_b")
+    if not os.path.exists(cli):
+        return None
+    tmp = tempfile.mkdtemp(prefix="pb_e2e_")
+    try:
+        synth.write_pair_files(os.path.join(tmp, "in"), GENOME, COVERAGE, SEED)
+        out = {"input": f"{GENOME / 1e6:g} Mbp x {COVERAGE:.0f}x PE{READ_LEN} seed {SEED}, two FASTQ files in the page cache", "runs": 2}
+        for name, extra in (("assemble_kmer_occ_only_wall_s", ["-kmer_occ_only"]), ("assemble_full_multik_wall_s", [])):
+            best = None
+            for _ in range(2):
+                t0 = time.perf_counter()
+                r = subprocess.run([cli, "assemble", "-k", str(K), *extra, "-o", os.path.join(tmp, "o"), "-f", os.path.join(tmp, "in_1.fq"),
+                                    os.path.join(tmp, "in_2.fq")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                dt = time.perf_counter() - t0
+                if r.returncode != 0:
+                    return {"error": f"{name}: exit status {r.returncode}"}
+                best = dt if best is None else min(best, dt)
+            out[name] = best
+        man = json.load(open(os.path.join(ROOT, "tests", "golden", "manifest.json")))["cfg3"]["runs"]["multik"]["files"]
+        md5 = {fn: hashlib.md5(open(os.path.join(tmp, fn.replace("out_", "o_", 1)), "rb").read()).hexdigest() for fn in man}
+        out["outputs_identical_to_reference_md5"] = all(md5[fn] == man[fn]["md5"] for fn in man)
+        out["reference_wall_s"] = {"assemble_full_multik": 1098, "where": "build container, 8 cores, -t 8 (tests/golden/manifest.json)"}
+        return out
+    finally:
+        subprocess.run(["rm", "-rf", tmp])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -220,6 +253,10 @@ def main():
                 out["cpu_baseline"] = cpu_baseline()
             except Exception as e:          # the baseline is a reported number, never a reason to lose the bench line
                 out["cpu_baseline"] = {"value": None, "unit": "k-mers/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+            try:
+                out["end_to_end"] = end_to_end()
+            except Exception as e:
+                out["end_to_end"] = {"error": str(e)}
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
