@@ -410,6 +410,17 @@ int run_assemble_gpu(const GpuAssembleOptions &opt)
     if (opt.repeat) throw std::runtime_error("-repeat is outside the scope of the device path (DESIGN.md section 1)");
     const auto t_start = std::chrono::steady_clock::now();
     Driver d(opt);
+    auto print_timing = [&]() {
+        if (!getenv("PB_TIMING")) return;
+        std::cerr << "\n#### STAGE WALL TIMES (s) ####" << std::endl;
+        for (const std::string &n : g_clock.order) std::cerr << n << "\t" << g_clock.acc[n] << std::endl;
+        std::cerr << "total\t" << std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() << std::endl;
+        std::cerr << "(device context creation, beside the parse\t" << d.create_s << ")" << std::endl;
+        auto epoch = [](std::chrono::system_clock::time_point t) { return std::chrono::duration<double>(t.time_since_epoch()).count(); };
+        std::cerr.precision(16);
+        std::cerr << "(epoch at entry\t" << epoch(std::chrono::system_clock::now()) - std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count()
+                  << ")\n(epoch at return\t" << epoch(std::chrono::system_clock::now()) << ")" << std::endl;
+    };
     d.min_log_p_join = log(1.0 - pow(10.0, -opt.safety));
     double bubble = atof(opt.bubble.c_str());
     std::get<0>(d.graphs).set_thresholds(bubble, opt.branch);
@@ -483,6 +494,7 @@ int run_assemble_gpu(const GpuAssembleOptions &opt)
     dispatch_w(opt.k0, [&](auto w) { d.template initial<decltype(w)::value>(); });
     if (opt.kmer_occ_only) {
         if (opt.verbose) std::cerr << "assemble completed!" << std::endl;
+        print_timing();
         return 0;
     }
     for (u64 i = 1; i < d.num_k; ++i) {
@@ -503,16 +515,7 @@ int run_assemble_gpu(const GpuAssembleOptions &opt)
         print_contigs(out, d.junctions, 1.0, d.avg_len, klast, "junction", true);
     }
     if (opt.verbose) std::cerr << "assemble completed!" << std::endl;
-    if (getenv("PB_TIMING")) {
-        std::cerr << "\n#### STAGE WALL TIMES (s) ####" << std::endl;
-        for (const std::string &n : g_clock.order) std::cerr << n << "\t" << g_clock.acc[n] << std::endl;
-        std::cerr << "total\t" << std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() << std::endl;
-        std::cerr << "(device context creation, beside the parse\t" << d.create_s << ")" << std::endl;
-        auto epoch = [](std::chrono::system_clock::time_point t) { return std::chrono::duration<double>(t.time_since_epoch()).count(); };
-        std::cerr.precision(16);
-        std::cerr << "(epoch at entry\t" << epoch(std::chrono::system_clock::now()) - std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count()
-                  << ")\n(epoch at return\t" << epoch(std::chrono::system_clock::now()) << ")" << std::endl;
-    }
+    print_timing();
     return 0;
 }
 
