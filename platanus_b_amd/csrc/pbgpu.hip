@@ -628,7 +628,7 @@ static int count_superk(pb_ctx *ctx, unsigned k, bool *done)
             const u64 exp_tiles = (u64)(est_rec / (double)nb1) / SK2_RCAP + 1;
             const unsigned blocks_per_sub = (unsigned)std::min<u64>(std::max<u64>(exp_tiles / 4, 1), 64);
             if (getenv("PB_PART2_GENERIC")) sk_part2_kernel<SkStore12><<<dim3(blocks_per_sub, (unsigned)nb1), SK_THREADS, 0, ctx->stream>>>(p);   // development / A-B
-            else sk_part2_raw12_kernel<<<dim3(blocks_per_sub, (unsigned)nb1), SK_THREADS, 0, ctx->stream>>>(p);
+            else sk_part2_raw12_kernel<SkStore12><<<dim3(blocks_per_sub, (unsigned)nb1), SK_THREADS, 0, ctx->stream>>>(p);
             t2.stop();
             LazyTimer t3(ctx, "bucket", 2);
             sk_bucket_kernel<<<grid_for(nb2, 1, 256 * 16), SK_ROLL_THREADS, 0, ctx->stream>>>(p, (u64 *)ctx->dist_keys.p, (u32 *)ctx->dist_counts.p, out_cap);
@@ -946,25 +946,23 @@ static int merge_begin_impl(pb_ctx *ctx, u64 cap)
      : (ctx)->W == 4 ? fn<4>(__VA_ARGS__) : fn<5>(__VA_ARGS__))
 
 // owner-side merge through the partition + LDS machinery (k <= 32); *done = false: the caller uses the table path
-static int merge_records_lds(pb_ctx *ctx, const void *dev_keys, const void *dev_counts, u64 n, bool *done)
+// G = SkStoreM12: 12-byte records (counts below 2^(32-B)); SkStore16 otherwise
+template <typename G>
+static int merge_records_lds_impl(pb_ctx *ctx, const void *dev_keys, const void *dev_counts, u64 n, unsigned B, bool *done)
 {
     int rc;
     *done = false;
-    if (n < (1ull << 20)) return PB_OK;
     SkParams p;
     p.abl = 0;
     p.k = ctx->k; p.m = 0; p.w = 0; p.L = 0;
-    unsigned B = 8;
-    while (((u64)1536 << B) < n && B < 20) ++B;            // hash-uniform buckets: mean <= 1536 distinct keys, the table takes 3840
-    if (((u64)1536 << B) < n) return PB_OK;
     p.B = B;
     p.l1 = B / 2;
     p.l2 = B - p.l1;
     const u64 nb1 = (1ull << p.l1) * PB_XCD, nb2 = 1ull << B;
     p.cap1 = n / nb1 * 3 / 2 + 4096;
     p.cap2 = (u32)(n / nb2 * 2 + 256);
-    if ((rc = ensure(ctx, ctx->part_bucket1, nb1 * p.cap1 * sizeof(SkRec))) != PB_OK) return rc;
-    if ((rc = ensure(ctx, ctx->part_bucket2, nb2 * (u64)p.cap2 * sizeof(SkRec))) != PB_OK) return rc;
+    if ((rc = ensure(ctx, ctx->part_bucket1, nb1 * p.cap1 * G::BYTES)) != PB_OK) return rc;
+    if ((rc = ensure(ctx, ctx->part_bucket2, nb2 * (u64)p.cap2 * G::BYTES)) != PB_OK) return rc;
     if ((rc = ensure(ctx, ctx->part_meta, (nb1 + 2 * nb2) * 4)) != PB_OK) return rc;
     p.spill_cap = 1ull << 16;
     if ((rc = ensure(ctx, ctx->part_spill, p.spill_cap * sizeof(SkRec))) != PB_OK) return rc;
@@ -984,10 +982,12 @@ static int merge_records_lds(pb_ctx *ctx, const void *dev_keys, const void *dev_
     HIPCHK(hipMemsetAsync(ctx->d_scalars.p, 0, 16 * 8, ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->part_meta.p, 0, (nb1 + 2 * nb2) * 4, ctx->stream));
     StageTimer tm(ctx, "merge");
-    mg_part1_kernel<<<grid_for((n + SK2_RCAP - 1) / SK2_RCAP, 1, 256 * 8), SK_THREADS, 0, ctx->stream>>>((const u64 *)dev_keys, (const u32 *)dev_counts, n, p);
+    mg_part1_kernel<G><<<grid_for((n + SK2_RCAP - 1) / SK2_RCAP, 1, 256 * 8), SK_THREADS, 0, ctx->stream>>>((const u64 *)dev_keys, (const u32 *)dev_counts, n, p);
     const u64 exp_tiles = n / nb1 / SK2_RCAP + 1;
-    sk_part2_kernel<SkStore16><<<dim3((unsigned)std::min<u64>(std::max<u64>(exp_tiles / 4, 1), 64), (unsigned)nb1), SK_THREADS, 0, ctx->stream>>>(p);
-    mg_bucket_kernel<<<grid_for(nb2, 1, 256 * 16), SK_ROLL_THREADS, 0, ctx->stream>>>(p, (u64 *)ctx->dist_keys.p, (u32 *)ctx->dist_counts.p, n);
+    const dim3 g2((unsigned)std::min<u64>(std::max<u64>(exp_tiles / 4, 1), 64), (unsigned)nb1);
+    if (G::BYTES == 12) sk_part2_raw12_kernel<SkStoreM12><<<g2, SK_THREADS, 0, ctx->stream>>>(p);
+    else sk_part2_kernel<SkStore16><<<g2, SK_THREADS, 0, ctx->stream>>>(p);
+    mg_bucket_kernel<G><<<grid_for(nb2, 1, 256 * 16), SK_ROLL_THREADS, 0, ctx->stream>>>(p, (u64 *)ctx->dist_keys.p, (u32 *)ctx->dist_counts.p, n);
     HIPCHK(hipGetLastError());
     u64 sc[9];
     HIPCHK(hipMemcpyAsync(sc, ctx->d_scalars.p, 72, hipMemcpyDeviceToHost, ctx->stream));
@@ -998,6 +998,20 @@ static int merge_records_lds(pb_ctx *ctx, const void *dev_keys, const void *dev_
     ctx->n_retained = 0;
     *done = true;
     return PB_OK;
+}
+
+static int merge_records_lds(pb_ctx *ctx, const void *dev_keys, const void *dev_counts, u64 n, bool *done)
+{
+    *done = false;
+    if (n < (1ull << 20)) return PB_OK;
+    unsigned B = 8;
+    while (((u64)1536 << B) < n && B < 20) ++B;            // hash-uniform buckets: mean <= 1536 distinct keys, the table takes 3840
+    if (((u64)1536 << B) < n) return PB_OK;
+    int rc;
+    if (B <= 16 && !getenv("PB_MERGE_16B")) {              // records of the exchange carry 16-bit counts: 12 bytes per record do
+        if ((rc = merge_records_lds_impl<SkStoreM12>(ctx, dev_keys, dev_counts, n, B, done)) != PB_OK || *done) return rc;
+    }
+    return merge_records_lds_impl<SkStore16>(ctx, dev_keys, dev_counts, n, B, done);
 }
 
 extern "C" {
