@@ -475,8 +475,9 @@ def test_merge_records_through_lds_tables(gpu, oracle_built, monkeypatch):
         assert np.array_equal(gk.reshape(-1), ok.reshape(-1)) and np.array_equal(gc, expect), table_path
 
 
-def test_two_ranks_share_one_gpu(oracle_built, tmp_path):
-    """The N > 1 step with real kernels: two processes on GPU 0 (gloo collectives staged through the host), each counting half
+@pytest.mark.parametrize("world,port", [(2, 29551), (4, 29552)])
+def test_two_ranks_share_one_gpu(world, port, oracle_built, tmp_path):
+    """The N > 1 step with real kernels: two (four) processes on GPU 0 (gloo collectives staged through the host), each counting half
     of the read pairs with the super-k-mer pass, exporting by owner, merging what it owns through the LDS-table merge.  The
     all-reduced histogram and the union of the two owner shards must equal the single-process oracle on all reads."""
     import json
@@ -486,8 +487,8 @@ def test_two_ranks_share_one_gpu(oracle_built, tmp_path):
     from platanus_b_amd import synth
     k, genome, cov, seed = 31, 300_000, 40.0, 33
     out = tmp_path / "res.json"
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29551",
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", PB_COUNT_PATH="superk")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "tests", "_gpu2_worker.py"), str(k), str(genome), str(cov), str(seed), str(out)]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
@@ -501,8 +502,8 @@ def test_two_ranks_share_one_gpu(oracle_built, tmp_path):
     assert res["hist_nonzero"] == {str(int(i)): int(ohist[i]) for i in np.nonzero(ohist)[0]}
     ok, ocn = oc.retain(1)
     assert res["n_distinct"] == len(ok)
-    keys = np.concatenate([np.load(str(out) + f".keys{r}.npy").reshape(-1) for r in range(2)])
-    counts = np.concatenate([np.load(str(out) + f".counts{r}.npy") for r in range(2)])
+    keys = np.concatenate([np.load(str(out) + f".keys{r}.npy").reshape(-1) for r in range(world)])
+    counts = np.concatenate([np.load(str(out) + f".counts{r}.npy") for r in range(world)])
     order = np.argsort(keys, kind="stable")
     assert np.array_equal(keys[order], ok.reshape(-1)) and np.array_equal(counts[order], ocn)
 
