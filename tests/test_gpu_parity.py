@@ -96,6 +96,35 @@ def test_ascii_input_uses_reference_char_table(gpu, oracle_built):
     assert np.array_equal(gk, ok) and np.array_equal(gc, ocn)
 
 
+def test_longest_read_the_reference_accepts(gpu, oracle_built, monkeypatch):
+    """common.h:465-467 / common.cpp:28: a read of 500,000 bases or more is an error (ReadError), 499,999 is the longest.  Such a read
+    spans 62 tiles of the partition kernel; three copies of it plus ordinary reads, counted by both passes, against the oracle."""
+    from platanus_b_amd.binding import PbError
+    rng = np.random.default_rng(12)
+    long_read = rng.integers(0, 4, 499_999).astype(np.uint8)
+    long_read[1000:1010] = 4
+    short = rng.integers(0, 4, (2000, 150)).astype(np.uint8)
+    codes = np.concatenate([long_read, long_read, short.reshape(-1), long_read])
+    off = np.concatenate([[0, 499_999, 999_998], 999_998 + 150 * np.arange(1, 2001), [999_998 + 300_000 + 499_999]]).astype(np.uint64)
+    oc = _oracle(codes, off, 32, oracle_built)
+    ohist, omax = oc.occ_hist()
+    ok, ocn = oc.retain(1)
+    for path in ("direct", "superk"):
+        monkeypatch.setenv("PB_COUNT_PATH", path)
+        g = gpu(0)
+        g.reads_append(codes, off)
+        hist = g.make_kmer_read_distribution(32)
+        assert (g.kernel_ms("part1") > 0) == (path == "superk")
+        assert np.array_equal(hist, ohist) and g.max_occ == omax
+        g.retain(1)
+        gk, gc = g.fetch_retained()
+        assert np.array_equal(gk, ok) and np.array_equal(gc, ocn)
+    g = gpu(0)
+    with pytest.raises(PbError) as e:
+        g.reads_append(np.zeros(500_000, dtype=np.uint8), np.array([0, 500_000], dtype=np.uint64))
+    assert e.value.code == -4 or "500000" in str(e.value)
+
+
 def test_saturation_at_65534(gpu):
     """counter.h:468-470: counts stop at UINT16_MAX-1; 70000 copies of one read."""
     read = np.array([0, 1, 2, 3] * 8 + [2, 2, 1], dtype=np.uint8)       # 35 bases -> 4 windows of 32

@@ -29,6 +29,8 @@ CASES = {
     "not_a_read_file": "hello\nworld\n",
     "fastq_without_plus": "@r0\nACGT\nIIII\n",
     "fasta_lower_case_later": ">a\nACGTTGCAAGGCTTAACCGGTTAAGGCCTTAGCAGCATCGACTAGCTAGCATCAGC\n" + ">b\nacgttgcaaggcttaaccggttaaggccttagcagcatcgactagctagcatcagc\n" * 5,
+    "read_of_499999_bases": "LONG:499999",
+    "read_of_500000_bases": "LONG:500000",
     "missing_file": None,
     "gzip_under_plain_name": b"gz",
 }
@@ -44,13 +46,21 @@ def main():
                 import gzip
                 with gzip.open(os.path.join(td, "in.fq"), "wt") as f:
                     f.write(READS)
+            elif isinstance(text, str) and text.startswith("LONG:"):      # the longest read the reference accepts is 499,999 bases (common.h:465-467)
+                import random
+                rnd = random.Random(7)
+                seq = "".join(rnd.choice("ACGT") for _ in range(int(text[5:])))
+                open(os.path.join(td, "in.fq"), "w").write(fq([seq] * 10))
             elif text is not None:
                 open(os.path.join(td, "in.fq"), "w").write(text)
             res = {}
             for who, b in bins:
                 d = os.path.join(td, who)
                 os.mkdir(d)
-                p = subprocess.run([b, "assemble", "-k", "21", "-t", "1", "-m", "1", "-o", "out", "-f", "../in.fq"], cwd=d, capture_output=True, text=True, timeout=300)
+                # (a 500 kbp read would send the multi-k schedule beyond k = 160: single k for the two long-read cases)
+                extra = ["-s", "0"] if isinstance(text, str) and text.startswith("LONG:") else []
+                p = subprocess.run([b, "assemble", "-k", "21", *extra, "-t", "1", "-m", "1", "-o", "out", "-f", "../in.fq"], cwd=d, capture_output=True, text=True,
+                                   timeout=300)
                 res[who] = (p.returncode, d, p.stderr[-300:])
             base = res["reference"] if "reference" in res else res["oracle"]
             line = [f"{who}: rc {res[who][0]} files {sorted(os.listdir(res[who][1]))}" for who, _ in bins]
