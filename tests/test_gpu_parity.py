@@ -49,6 +49,29 @@ def test_count_matches_oracle_all_key_widths(k, gpu, oracle_built):
         assert np.array_equal(gc, ocn)
 
 
+@pytest.mark.parametrize("k", [159, 160])
+def test_largest_k_of_the_fixed_width_kmers(k, gpu, oracle_built):
+    """k = 160 is the largest k of the reference's fixed-width key types (Kmer159 = five 64-bit words, kmer.h / binstr.h); 161 and more is
+    refused by the library.  PE250 reads, counts and retained keys against the oracle."""
+    from platanus_b_amd import synth
+    from platanus_b_amd.binding import PbError
+    r1, r2 = synth.make_reads(20_000, 40, seed=300 + k, read_len=250, n_rate=0.001)
+    codes = np.concatenate([r1, r2])
+    n, L = codes.shape
+    oc = _oracle(codes, np.arange(n + 1, dtype=np.uint64) * np.uint64(L), k, oracle_built)
+    ohist, omax = oc.occ_hist()
+    g = gpu(0)
+    g.reads_append_matrix(codes)
+    hist = g.make_kmer_read_distribution(k)
+    assert np.array_equal(hist, ohist) and g.max_occ == omax
+    ok, ocn = oc.retain(2)
+    assert g.retain(2) == len(ok)
+    gk, gc = g.fetch_retained()
+    assert np.array_equal(gk, ok) and np.array_equal(gc, ocn)
+    with pytest.raises(PbError):
+        g.make_kmer_read_distribution(161)
+
+
 def test_ragged_reads_empty_reads_and_n_runs(gpu, oracle_built):
     rng = np.random.default_rng(7)
     lens = np.concatenate([[0, 1, 31, 32, 33, 0, 64, 499, 32, 0, 150, 151], rng.integers(0, 300, 2000)]).astype(np.uint64)
