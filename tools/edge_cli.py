@@ -31,6 +31,7 @@ CASES = {
     "fasta_lower_case_later": ">a\nACGTTGCAAGGCTTAACCGGTTAAGGCCTTAGCAGCATCGACTAGCTAGCATCAGC\n" + ">b\nacgttgcaaggcttaaccggttaaggccttagcagcatcgactagctagcatcagc\n" * 5,
     "read_of_499999_bases": "LONG:499999",
     "read_of_500000_bases": "LONG:500000",
+    "eleven_input_files": "MULTI:11",
     "missing_file": None,
     "gzip_under_plain_name": b"gz",
 }
@@ -42,10 +43,30 @@ def main():
     bad = 0
     for name, text in CASES.items():
         with tempfile.TemporaryDirectory() as td:
+            files = ["../in.fq"]
             if text == b"gz":
                 import gzip
                 with gzip.open(os.path.join(td, "in.fq"), "wt") as f:
                     f.write(READS)
+            elif isinstance(text, str) and text.startswith("MULTI:"):       # more files than the CLI parses at once (8): FASTQ, FASTA and gzip mixed
+                import gzip
+                import random
+                rnd = random.Random(11)
+                genome = "".join(rnd.choice("ACGT") for _ in range(3000))
+                n_files = int(text[6:])
+                for fi in range(n_files):
+                    reads = []
+                    for _ in range(150):
+                        a = rnd.randrange(0, len(genome) - 100)
+                        reads.append(genome[a:a + 100])
+                    fname = os.path.join(td, f"in{fi}.fq")
+                    body = fq(reads) if fi % 3 != 1 else "".join(f">r{i}\n{r}\n" for i, r in enumerate(reads))
+                    if fi % 4 == 3:
+                        with gzip.open(fname, "wt") as f:
+                            f.write(body)
+                    else:
+                        open(fname, "w").write(body)
+                files = [f"../in{fi}.fq" for fi in range(n_files)]
             elif isinstance(text, str) and text.startswith("LONG:"):      # the longest read the reference accepts is 499,999 bases (common.h:465-467)
                 import random
                 rnd = random.Random(7)
@@ -59,7 +80,7 @@ def main():
                 os.mkdir(d)
                 # (a 500 kbp read would send the multi-k schedule beyond k = 160: single k for the two long-read cases)
                 extra = ["-s", "0"] if isinstance(text, str) and text.startswith("LONG:") else []
-                p = subprocess.run([b, "assemble", "-k", "21", *extra, "-t", "1", "-m", "1", "-o", "out", "-f", "../in.fq"], cwd=d, capture_output=True, text=True,
+                p = subprocess.run([b, "assemble", "-k", "21", *extra, "-t", "1", "-m", "1", "-o", "out", "-f", *files], cwd=d, capture_output=True, text=True,
                                    timeout=300)
                 res[who] = (p.returncode, d, p.stderr[-300:])
             base = res["reference"] if "reference" in res else res["oracle"]
