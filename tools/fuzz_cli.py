@@ -57,6 +57,16 @@ def main():
             args = ["-k", str(k), "-s", str(int(rng.choice([0, 5, 10, 20]))), "-u", str(rng.choice(["0", "0", "1"])), "-m", "1"]
             if rng.random() < 0.3:
                 args += ["-n", str(int(rng.integers(1, 4)))]
+            if rng.random() < 0.25:                              # the options of the k schedule and of the cleaning steps
+                args += ["-c", str(int(rng.integers(1, 5)))]
+            if rng.random() < 0.25:
+                args += ["-d", str(rng.choice(["0.3", "0.5", "0.8"]))]
+            if rng.random() < 0.25:
+                args += ["-K", str(rng.choice(["0.3", "0.5", "0.7"]))]
+            if rng.random() < 0.2:
+                args += ["-a", str(rng.choice(["5", "10", "20"]))]
+            if rng.random() < 0.2:
+                args += ["-e", str(rng.choice(["20", "45"]))]
             outs = {}
             for name, binary, extra in (("orc", ORC, []), ("gpu", GPU, [])):
                 d = os.path.join(td, name)
