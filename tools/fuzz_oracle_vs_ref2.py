@@ -1,0 +1,62 @@
+"""Development aid (CPU, build container only): the oracle's `kmer_divide` and `merge` commands against the REAL reference binary
+(oracle/_ref/platanus_b) on the contigs and the k-mer occurrence table the reference itself makes from random heterozygous read
+sets, with random options.  usage: python tools/fuzz_oracle_vs_ref2.py [n_cases] [seed]"""
+import filecmp
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+GPU = os.path.join(ROOT, "oracle", "_ref", "platanus_b")
+ORC = os.path.join(ROOT, "oracle", "pb_oracle")
+
+
+def run(binary, args, cwd):
+    return subprocess.run([binary, *args], cwd=cwd, capture_output=True, text=True, timeout=600)
+
+
+def main():
+    from platanus_b_amd import synth
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    bad = 0
+    for case in range(n_cases):
+        G = int(rng.integers(6_000, 25_000))
+        with tempfile.TemporaryDirectory() as td:
+            synth.write_pair_files(os.path.join(td, "in"), G, float(rng.choice([30, 60])), int(rng.integers(1, 1 << 30)), err=float(rng.choice([0.002, 0.01])),
+                                   n_rate=0.0, het=float(rng.choice([0.0, 0.004, 0.01])))
+            assert run(GPU, ["assemble", "-k", "32", "-t", "1", "-m", "1", "-o", "asm", "-f", "in_1.fq", "in_2.fq"], td).returncode == 0
+            assert run(GPU, ["assemble", "-k", "32", "-t", "1", "-m", "1", "-n", "1", "-kmer_occ_only", "-o", "occ", "-f", "in_1.fq", "in_2.fq"], td).returncode == 0
+            kd = [[], ["-mask"], ["-r", str(round(float(rng.uniform(0.05, 0.9)), 2))], ["-mask", "-R", str(round(float(rng.uniform(1.1, 3.0)), 2))]][int(rng.integers(0, 4))]
+            mg = ["-k", str(round(float(rng.uniform(0.2, 1.0)), 2)), "-l", str(round(float(rng.uniform(0.5, 2.0)), 2)), "-u", str(rng.choice(["0", "1"])), "-m", "1"]
+            ok = True
+            for cmd, args, inputs in (("kmer_divide", kd, ["-k", "../occ_kmer_occ.bin", "-f", "../asm_contig.fa"]), ("merge", mg, ["-f", "../asm_contig.fa"])):
+                dirs = {}
+                for name, binary in (("orc", ORC), ("gpu", GPU)):          # "gpu" = the reference binary here
+                    d = os.path.join(td, f"{cmd}_{name}")
+                    os.mkdir(d)
+                    dirs[name] = (run(binary, [cmd, *args, "-o", "out", *inputs], d).returncode, d)
+                if dirs["orc"][0] != dirs["gpu"][0]:
+                    ok = False
+                    print(f"  {cmd}: rc {dirs['orc'][0]} vs {dirs['gpu'][0]}")
+                    continue
+                for fn in sorted(os.listdir(dirs["orc"][1])):
+                    b = os.path.join(dirs["gpu"][1], fn)
+                    if not os.path.exists(b) or not filecmp.cmp(os.path.join(dirs["orc"][1], fn), b, shallow=False):
+                        ok = False
+                        print(f"  {cmd}: {fn} differs")
+            if not ok:
+                bad += 1
+                print(f"MISMATCH case {case}: G={G} kmer_divide {' '.join(kd)} merge {' '.join(mg)}", flush=True)
+            else:
+                print(f"case {case}: ok (G={G} kmer_divide {' '.join(kd)}; merge {' '.join(mg)})", flush=True)
+    print(f"{n_cases} cases, {bad} mismatches")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
