@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, case_reads
+from conftest import GOLDEN, ROOT, case_reads
 
 
 def _md5(path):
@@ -124,3 +124,16 @@ def test_repeat_mode_has_no_reference_output(tmp_path, oracle_built):
         assert p.returncode == -signal.SIGSEGV, (b, p.returncode)
         assert "extracting reads (containing kmer used in contig assemble)..." in p.stderr.splitlines()[-1]
         assert not os.path.exists(tmp_path / "out_contig.fa")
+
+
+def test_oracle_cli_equals_real_reference_on_random_options(oracle_built):
+    """tools/fuzz_oracle_vs_ref.py, a slice: where the real reference binary was built (oracle/_ref, build container only) the oracle
+    CLI must give the same exit status and files for random read sets and random -k -s -u -n -c -d -K -a -e."""
+    import subprocess
+    import sys
+    ref = os.path.join(ROOT, "oracle", "_ref", "platanus_b")
+    if not os.path.exists(ref):
+        pytest.skip("oracle/_ref/platanus_b not built (no /root/reference here)")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_oracle_vs_ref.py"), "4", "77"], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+    assert "4 cases, 0 mismatches" in p.stdout
