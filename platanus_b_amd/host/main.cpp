@@ -3,6 +3,7 @@
 #include "assemble_gpu.hpp"
 #include "kmer_divide.hpp"
 #include "merge.hpp"
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include "errors.hpp"
@@ -31,6 +32,33 @@ static void usage()
               << "\n\nOutputs:\n    PREFIX_contig.fa\n    PREFIX_kmerFrq.tsv\n\nNote, PREFIX is specified by -o\n" << std::endl;
 }
 
+// main.cpp:49-63 (ShowVersion / ShowArgs) and main.cpp:128-147: the reference frames every run's stderr with its version, the command
+// line, and the process's peak memory; kept so that logs look the same (1.3.2 = the version of the command line implemented here)
+static void show_version_and_args(int argc, char **argv)
+{
+    std::cerr << "platanus_b version: 1.3.2" << std::endl;
+    for (int i = 0; i < argc; ++i) std::cerr << argv[i] << " ";
+    std::cerr << std::endl << std::endl;
+}
+
+static int process_information(int rc)
+{
+    unsigned long long vmpeak = 0, vmhwm = 0;
+    FILE *f = fopen("/proc/self/status", "r");
+    if (f) {
+        char line[256];
+        while (fgets(line, sizeof line, f)) {
+            if (strncmp(line, "VmPeak", 6) == 0) vmpeak = (unsigned long long)atoi(line + 8);
+            else if (strncmp(line, "VmHWM", 5) == 0) vmhwm = (unsigned long long)atoi(line + 8);
+        }
+        fclose(f);
+    }
+    fprintf(stderr, "\n#### PROCESS INFORMATION ####\n");
+    fprintf(stderr, "VmPeak:      %10.3f GByte\n", vmpeak / 1048576.0);
+    fprintf(stderr, "VmHWM:       %10.3f GByte\n", vmhwm / 1048576.0);
+    return rc;
+}
+
 namespace pbh { int run_kmer_divide_gpu(const DivideOptions &opt, int device, bool verbose); int run_merge_gpu(const MergeOptions &opt, int device, bool verbose); }
 
 static int main_merge(int argc, char **argv)             // options: merge.cpp:29-39
@@ -53,7 +81,7 @@ static int main_merge(int argc, char **argv)             // options: merge.cpp:2
         else { std::cerr << "\nUsage: platanus_b merge [Options] (-o -f -c -k -l -u -d -m -tmp)" << std::endl; return 1; }
     }
     try {
-        return pbh::run_merge_gpu(o, device, true);
+        return process_information(pbh::run_merge_gpu(o, device, true));
     } catch (const std::exception &e) {
         std::cerr << "Error: " << e.what() << std::endl;
         return 2;
@@ -81,7 +109,7 @@ static int main_kmer_divide(int argc, char **argv)       // options: kmer_divide
     if (o.files.empty()) { std::cerr << "Error: not specified contig file!!" << std::endl; return 1; }
     if (o.occ_file.empty()) { std::cerr << "Error: not specified kmer occurrence file!!!" << std::endl; return 1; }
     try {
-        return pbh::run_kmer_divide_gpu(o, device, true);
+        return process_information(pbh::run_kmer_divide_gpu(o, device, true));
     } catch (const std::exception &e) {
         std::cerr << "Error: " << e.what() << std::endl;
         return 2;
@@ -90,6 +118,8 @@ static int main_kmer_divide(int argc, char **argv)       // options: kmer_divide
 
 int main(int argc, char **argv)
 {
+    show_version_and_args(argc, argv);
+    if (argc >= 2 && strcmp(argv[1], "-v") == 0) return 0;                       // main.cpp:77-79
     if (argc >= 2 && strcmp(argv[1], "kmer_divide") == 0) return main_kmer_divide(argc, argv);
     if (argc >= 2 && strcmp(argv[1], "merge") == 0) return main_merge(argc, argv);
     if (argc < 2 || strcmp(argv[1], "assemble") != 0) {
@@ -121,9 +151,9 @@ int main(int argc, char **argv)
     }
     if (o.files.empty()) { usage(); return 1; }
     try {
-        return pbh::run_assemble_gpu(o);
-    } catch (const pbh::RefError &e) {           // the reference's exceptions: message, exit status = error id (main.cpp:118-127)
-        std::cerr << e.what() << std::endl;
+        return process_information(pbh::run_assemble_gpu(o));
+    } catch (const pbh::RefError &e) {           // the reference's exceptions: message, exit status = error id (main.cpp:118-127, common.h:97-100)
+        std::cerr << "Error(" << e.id << "): " << e.what() << std::endl;
         return e.id;
     } catch (const std::exception &e) {
         std::cerr << "Error: " << e.what() << std::endl;
