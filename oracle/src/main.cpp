@@ -119,10 +119,14 @@ int main(int argc, char **argv)
 {
     using namespace pbo;
     if (argc >= 2 && strcmp(argv[1], "merge") == 0) {
-        try { return oracle_merge(argc, argv); } catch (const std::exception &e) { std::cerr << "Error: " << e.what() << std::endl; return 2; }
+        try { return oracle_merge(argc, argv); }
+        catch (const pbh::RefError &e) { std::cerr << "Error(" << e.id << "): " << e.what() << std::endl; return e.id; }
+        catch (const std::exception &e) { std::cerr << "Error: " << e.what() << std::endl; return 2; }
     }
     if (argc >= 2 && strcmp(argv[1], "kmer_divide") == 0) {
-        try { return oracle_kmer_divide(argc, argv); } catch (const std::exception &e) { std::cerr << "Error: " << e.what() << std::endl; return 2; }
+        try { return oracle_kmer_divide(argc, argv); }
+        catch (const pbh::RefError &e) { std::cerr << "Error(" << e.id << "): " << e.what() << std::endl; return e.id; }
+        catch (const std::exception &e) { std::cerr << "Error: " << e.what() << std::endl; return 2; }
     }
     if (argc < 2 || strcmp(argv[1], "assemble") != 0) {
         std::cerr << "usage: pb_oracle assemble [platanus_b assemble options]" << std::endl;
@@ -155,7 +159,7 @@ int main(int argc, char **argv)
         for (const std::string &f : o.files) read_fastx(f, reads);
         return run_assemble(o, reads);
     } catch (const pbh::RefError &e) {           // main.cpp:118-127: message, exit status = error id
-        std::cerr << e.what() << std::endl;
+        std::cerr << "Error(" << e.id << "): " << e.what() << std::endl;
         return e.id;
     } catch (const std::exception &e) {
         std::cerr << "Error: " << e.what() << std::endl;

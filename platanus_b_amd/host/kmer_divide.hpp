@@ -5,6 +5,7 @@
 // in this header is the host logic around them, shared with the oracle, which fills the same arrays with CPU look-ups.
 #pragma once
 #include "kmer.hpp"
+#include "errors.hpp"
 #include <algorithm>
 #include <cfloat>
 #include <cstdio>
@@ -50,7 +51,7 @@ inline u64 find_number_after(const char *line, const std::string &tag)
 inline void read_contig_fasta(const std::string &path, ContigSet &cs, bool first_file, u64 &read_length, u64 &max_k)
 {
     std::ifstream ifs(path);
-    if (!ifs) throw std::runtime_error("cannot open " + path);
+    if (!ifs) throw file_error(path);
     std::string line, contig, header;
     bool have = false;
     auto push = [&]() {
@@ -86,7 +87,7 @@ inline void read_contig_fasta(const std::string &path, ContigSet &cs, bool first
 inline void read_kmer_occ(const std::string &path, unsigned &k, std::vector<u64> &keys, std::vector<u16> &counts)
 {
     FILE *f = fopen(path.c_str(), "rb");
-    if (!f) throw std::runtime_error("cannot open " + path);
+    if (!f) throw file_error(path);
     u64 hdr[2];
     if (fread(hdr, 8, 2, f) != 2) { fclose(f); throw std::runtime_error("truncated " + path); }
     k = (unsigned)hdr[0];

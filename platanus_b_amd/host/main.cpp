@@ -82,6 +82,9 @@ static int main_merge(int argc, char **argv)             // options: merge.cpp:2
     }
     try {
         return process_information(pbh::run_merge_gpu(o, device, true));
+    } catch (const pbh::RefError &e) {
+        std::cerr << "Error(" << e.id << "): " << e.what() << std::endl;
+        return e.id;
     } catch (const std::exception &e) {
         std::cerr << "Error: " << e.what() << std::endl;
         return 2;
@@ -110,6 +113,9 @@ static int main_kmer_divide(int argc, char **argv)       // options: kmer_divide
     if (o.occ_file.empty()) { std::cerr << "Error: not specified kmer occurrence file!!!" << std::endl; return 1; }
     try {
         return process_information(pbh::run_kmer_divide_gpu(o, device, true));
+    } catch (const pbh::RefError &e) {
+        std::cerr << "Error(" << e.id << "): " << e.what() << std::endl;
+        return e.id;
     } catch (const std::exception &e) {
         std::cerr << "Error: " << e.what() << std::endl;
         return 2;

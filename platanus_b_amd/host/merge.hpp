@@ -4,6 +4,7 @@
 // multi-k rounds already use (value = max(contig coverage, -c)).  This header holds the host parts shared with the oracle.
 #pragma once
 #include "kmer.hpp"
+#include "errors.hpp"
 #include <algorithm>
 #include <fstream>
 #include <sstream>
@@ -35,7 +36,7 @@ struct MergeContigs {
 inline void read_contigs_cut_n(const std::string &path, u64 min_len, MergeContigs &mc)
 {
     std::ifstream ifs(path);
-    if (!ifs) throw std::runtime_error("cannot open " + path);
+    if (!ifs) throw file_error(path);
     std::string line, contig;
     bool have = false, first = true;
     u16 cov = 0;

@@ -12,6 +12,7 @@
 // clear() keeps the bucket array across rounds.
 #pragma once
 #include "kmer.hpp"
+#include "errors.hpp"
 #include <sstream>
 #include <algorithm>
 #include <array>
@@ -90,7 +91,7 @@ inline void print_contigs(const std::string &path, const std::vector<ContigRecor
                           double avg_len, long max_k, const char *prefix, bool append)
 {
     FILE *f = fopen(path.c_str(), append ? "a" : "w");
-    if (!f) throw std::runtime_error("cannot open " + path);
+    if (!f) throw file_error(path);
     u64 num = 0;
     std::string line;
     for (const ContigRecord &r : recs) {
@@ -120,7 +121,7 @@ inline void print_contigs(const std::string &path, const std::vector<ContigRecor
 inline void print_bubbles(const std::string &path, const std::vector<ContigRecord> &recs, double ratio)
 {
     FILE *f = fopen(path.c_str(), "w");
-    if (!f) throw std::runtime_error("cannot open " + path);
+    if (!f) throw file_error(path);
     u64 num = 0;
     for (const ContigRecord &r : recs) {
         const u16 occ = r.cov * ratio + 0.5;
