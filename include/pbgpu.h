@@ -49,6 +49,14 @@ typedef struct pb_ctx pb_ctx;
 int         pb_create(int device_id, pb_ctx **out);
 void        pb_destroy(pb_ctx *ctx);
 const char *pb_last_error(const pb_ctx *ctx);          /* ctx may be NULL: error of the last failed pb_create */
+/* Choice between equivalent implementations of a call (tests, A/B timing).  No option changes a result; the library reads no
+ * environment variable for this.  Not in the reference (its only knobs are -t and -m).
+ *   "count_path"      0 = by input size (default), 1 = direct pass (one lane per window, global table), 2 = super-k-mer pass (k <= 32)
+ *   "sk_bucket_bits"  0 = by input size, 2..18 = bucket bits of the super-k-mer pass;  "sk_l1_bits" 0 = half of them, 1..9
+ *   "merge_table" / "merge_16b"  1 = owner-side merge through the global table / with 16-byte records
+ *   "chain_rank_full" 1 = pointer jumping over all chain states;  "grid_cap" n = cap on the grid of the direct counting kernel
+ *   "verbose"         1 = one line per super-k-mer pass attempt on stderr (bucket bits, records, flagged buckets, spilled records) */
+int         pb_set_option(pb_ctx *ctx, const char *name, long value);
 /* name, CU count, HBM bytes of the context's device (for reports; not in the reference) */
 int         pb_device_info(const pb_ctx *ctx, char *name, size_t name_cap, int *n_cu, uint64_t *hbm_bytes);
 

@@ -51,6 +51,7 @@ def load_library() -> C.CDLL:
     lib.pb_destroy.restype = None
     lib.pb_last_error.argtypes = [vp]
     lib.pb_last_error.restype = C.c_char_p
+    lib.pb_set_option.argtypes = [vp, C.c_char_p, C.c_long]
     lib.pb_device_info.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), u64p]
     lib.pb_reads_append.argtypes = [vp, vp, vp, C.c_uint64, C.c_int]
     lib.pb_reads_clear.argtypes = [vp]
@@ -82,6 +83,9 @@ def words_for_k(k: int) -> int:
 class GpuCounter:
     """Device-side Counter<KMER> (counter.h:36-1056) for one GPU."""
 
+    # pb_set_option calls applied to every new context (tests force a counting path on inputs the library would route elsewhere)
+    default_options: dict = {}
+
     def __init__(self, device: int = 0):
         self.lib = load_library()
         self.h = C.c_void_p()
@@ -94,6 +98,8 @@ class GpuCounter:
         self.n_instances = 0
         self.n_distinct = 0
         self.n_retained = 0
+        for name, value in self.default_options.items():
+            self.set_option(name, value)
 
     def close(self):
         if self.h:
@@ -109,6 +115,10 @@ class GpuCounter:
     def _chk(self, rc: int):
         if rc != 0:
             raise PbError(rc, self.lib.pb_last_error(self.h).decode())
+
+    def set_option(self, name: str, value: int):
+        """pb_set_option: choice between equivalent implementations (e.g. "count_path" 0 auto / 1 direct / 2 super-k-mer pass)."""
+        self._chk(self.lib.pb_set_option(self.h, name.encode(), int(value)))
 
     def device_info(self):
         name = C.create_string_buffer(256)

@@ -125,6 +125,11 @@ struct pb_ctx {
     u64 sk_flagged = 0, sk_spilled = 0, sk_extra_for = 0;
     u64 hist_done = 0;              // leading records of the distinct arrays already tallied into d_hist
     unsigned sk_bits = 0, sk_extra_bits = 0;       // bucket bits used; extra bits that an earlier pass over the same stream needed
+    // pb_set_option: choices between equivalent implementations (tests and A/B runs; no option changes a result)
+    int opt_count_path = 0;         // 0 = by input size, 1 = direct (global table), 2 = super-k-mer pass
+    int sk_force_bits = 0;          // bucket bits of the super-k-mer pass (0 = by input size)
+    int sk_force_l1 = 0;            // ... of which level 1 (0 = half)
+    int opt_merge_table = 0, opt_merge_16b = 0, opt_chain_rank_full = 0, opt_grid_cap = 0, opt_verbose = 0;
 
     // owner exchange (X1)
     DevBuf exp_keys, exp_counts, merge_table;
@@ -297,6 +302,22 @@ void pb_destroy(pb_ctx *ctx)
 }
 
 const char *pb_last_error(const pb_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int pb_set_option(pb_ctx *ctx, const char *name, long value)
+{
+    if (!ctx || !name) return PB_EINVAL;
+    const std::string n(name);
+    if (n == "count_path" && value >= 0 && value <= 2) ctx->opt_count_path = (int)value;
+    else if (n == "sk_bucket_bits" && (value == 0 || (value >= 2 && value <= 18))) ctx->sk_force_bits = (int)value;
+    else if (n == "sk_l1_bits" && value >= 0 && value <= 9) ctx->sk_force_l1 = (int)value;
+    else if (n == "merge_table" && (value == 0 || value == 1)) ctx->opt_merge_table = (int)value;
+    else if (n == "merge_16b" && (value == 0 || value == 1)) ctx->opt_merge_16b = (int)value;
+    else if (n == "chain_rank_full" && (value == 0 || value == 1)) ctx->opt_chain_rank_full = (int)value;
+    else if (n == "verbose" && (value == 0 || value == 1)) ctx->opt_verbose = (int)value;
+    else if (n == "grid_cap" && value >= 0 && value <= (1 << 20)) ctx->opt_grid_cap = (int)value;
+    else { ctx->err = "pb_set_option: unknown option or value out of range: " + n; return PB_EINVAL; }
+    return PB_OK;
+}
 
 int pb_device_info(const pb_ctx *ctx, char *name, size_t name_cap, int *n_cu, uint64_t *hbm_bytes)
 {
@@ -515,7 +536,6 @@ static int count_direct(pb_ctx *ctx, unsigned k)
     u64 cap = 1ull << 16;
     while (cap < windows / 2) cap <<= 1;
     float ms_count = 0;
-    const char *gc = getenv("PB_GRIDCAP");
     for (int attempt = 0; attempt < 8; ++attempt) {
         if ((rc = ensure(ctx, ctx->table, cap * PB_SLOT_WORDS(W) * 8)) != PB_OK) return rc;
         ctx->table_cap = cap;
@@ -528,7 +548,7 @@ static int count_direct(pb_ctx *ctx, unsigned k)
         }
         StageTimer tm(ctx, "count");
         if (ctx->stream_len >= k) {
-            count_kernel<W><<<grid_for(ctx->stream_len, 256, gc ? atoi(gc) : 256 * 32), 256, 0, ctx->stream>>>(
+            count_kernel<W><<<grid_for(ctx->stream_len, 256, ctx->opt_grid_cap ? (unsigned)ctx->opt_grid_cap : 256 * 32), 256, 0, ctx->stream>>>(
                 (const u64 *)ctx->packed.p, cur_mask(ctx), ctx->stream_len, k, tv, 256u, (u64 *)ctx->d_scalars.p);
         }
         HIPCHK(hipGetLastError());
@@ -555,44 +575,34 @@ static int count_superk(pb_ctx *ctx, unsigned k, bool *done)
     const u64 lost = (u64)k * ctx->n_reads;
     const u64 windows = ctx->stream_len > lost + 4096 ? ctx->stream_len - lost : ctx->stream_len;
     SkParams p;
-    p.abl = getenv("PB_ABLATE") ? atoi(getenv("PB_ABLATE")) : 0;
     p.k = k;
     p.m = k < SK_M ? k : SK_M;
     p.w = k - p.m + 1;
-    // ~12 K windows per final bucket: with sequencing-depth data that is 1-2 K distinct keys for the 4096-slot LDS table.
-    // Low-coverage data has more distinct keys per window; the pass is then repeated with 4x the buckets (see below) and
-    // the context remembers what worked.
+    // ~SK_SLOTS * 3 windows per final bucket: with sequencing-depth data that is SK_SLOTS / 2 or fewer distinct keys for the
+    // SK_SLOTS-slot LDS table.  Low-coverage data has more distinct keys per window; the pass is then repeated with 4x the
+    // buckets (see below) and the context remembers what worked.
     unsigned B = 8;
-    while (((u64)12288 << B) < windows && B < 18) ++B;
+    while (((u64)(SK_SLOTS * 3) << B) < windows && B < 18) ++B;
     if (ctx->sk_extra_bits && ctx->sk_extra_for == windows) B = std::min(18u, B + ctx->sk_extra_bits);
     bool forced_b = false;
-    if (const char *fb = getenv("PB_FORCE_SKB")) {            // tests: other bucket counts on small inputs
-        const int v = atoi(fb);
-        if (v >= 2 && v <= 18) { B = (unsigned)v; forced_b = true; }
-    }
+    if (ctx->sk_force_bits >= 2 && ctx->sk_force_bits <= 18) { B = (unsigned)ctx->sk_force_bits; forced_b = true; }
     u64 fcap = 1ull << 20;
     for (int attempt = 0; attempt < 12; ++attempt) {
         p.B = B;
         p.l1 = B / 2;
-        if (const char *e = getenv("PB_SK_L1")) { const int v = atoi(e); if (v >= 1 && v < (int)B && v <= 9 && (int)B - v <= 9) p.l1 = (unsigned)v; }   // development
+        if (ctx->sk_force_l1 >= 1 && ctx->sk_force_l1 < (int)B && (int)B - ctx->sk_force_l1 <= 9) p.l1 = (unsigned)ctx->sk_force_l1;
         p.l2 = B - p.l1;
-        const int max_bases = 32 + (int)(29 - B) / 2;             // 96 bits: 32 bases + (32 - 3 (length - 1) - B (bucket)) / 2 more
-        int L = max_bases - (int)k + 1;
-        if (L > SK_LCAP) L = SK_LCAP;
-        if (const char *lc = getenv("PB_SK_LCAP")) { const int v = atoi(lc); if (v >= 1 && v <= SK_LCAP && v <= max_bases - (int)k + 1) L = v; }
-        if (L < 1) return PB_OK;
-        p.L = (unsigned)L;
-        // expected windows per record: a new minimizer every (w+1)/2 windows, a forced start every L
-        const double avg_len = 1.0 / (2.0 / (p.w + 1.0) + 1.0 / p.L);
-        const double est_rec = (double)windows / avg_len;
+        // expected windows per record: a run ends when a smaller m-mer enters the window or the minimizer leaves it -- (w + 1) / 2
+        // windows on random sequence; every read start and every unknown base cuts one more
+        const double est_rec = (double)windows * 2.0 / (p.w + 1.0) + 2.0 * (double)ctx->n_reads;
         const u64 nb1 = (1ull << p.l1) * PB_XCD, nb2 = 1ull << B;
         p.cap1 = (u64)(est_rec / (double)nb1 * 1.5) + 4096;
         p.cap2 = (u32)std::min<double>(est_rec / (double)nb2 * 3.0 + 256.0, 1e9);   // minimizer sites are few per bucket: sizes vary a lot
-        if ((rc = ensure(ctx, ctx->part_bucket1, nb1 * p.cap1 * SkStore12::BYTES)) != PB_OK) return rc;
-        if ((rc = ensure(ctx, ctx->part_bucket2, (nb2 * (u64)p.cap2 + 1024) * SkStore12::BYTES)) != PB_OK) return rc;
+        if ((rc = ensure(ctx, ctx->part_bucket1, nb1 * p.cap1 * SkStore16::BYTES)) != PB_OK) return rc;
+        if ((rc = ensure(ctx, ctx->part_bucket2, (nb2 * (u64)p.cap2 + 1024) * SkStore16::BYTES)) != PB_OK) return rc;
         if ((rc = ensure(ctx, ctx->part_meta, (nb1 + 2 * nb2) * 4)) != PB_OK) return rc;
         p.spill_cap = std::max<u64>((u64)(est_rec / 16), 1ull << 16);
-        if ((rc = ensure(ctx, ctx->part_spill, p.spill_cap * SkStore12::BYTES)) != PB_OK) return rc;
+        if ((rc = ensure(ctx, ctx->part_spill, p.spill_cap * SkStore16::BYTES)) != PB_OK) return rc;
         p.spill = ctx->part_spill.p;
         p.bucket1 = ctx->part_bucket1.p;
         p.bucket2 = ctx->part_bucket2.p;
@@ -620,18 +630,19 @@ static int count_superk(pb_ctx *ctx, unsigned k, bool *done)
             // one host synchronisation for the three kernels (the flags are needed before anything else is decided)
             LazyTimer t1(ctx, "part1", 0);
             const u64 n_tiles = (ctx->stream_len + SK_OWN - 1) / SK_OWN;
-            sk_part1_kernel<<<grid_for(n_tiles, 1, 256 * 8), SK_THREADS, 0, ctx->stream>>>((const u64 *)ctx->packed.p, cur_mask(ctx), ctx->stream_len,
-                                                                                        (ctx->stream_len + 63) / 64 + PB_STREAM_PAD_WORDS64, p);
+            const u64 nw64 = (ctx->stream_len + 63) / 64 + PB_STREAM_PAD_WORDS64;
+            if (k == 32) sk_part1_kernel<32><<<grid_for(n_tiles, 1, 256 * 8), SK_THREADS, 0, ctx->stream>>>((const u64 *)ctx->packed.p, cur_mask(ctx), ctx->stream_len, nw64, p);
+            else sk_part1_kernel<0><<<grid_for(n_tiles, 1, 256 * 8), SK_THREADS, 0, ctx->stream>>>((const u64 *)ctx->packed.p, cur_mask(ctx), ctx->stream_len, nw64, p);
             t1.stop();
             LazyTimer t2(ctx, "part2", 1);
             // a few blocks per sub-stream, each striding over its tiles (most of cap1 is head-room: one block per tile would be mostly empty blocks)
-            const u64 exp_tiles = (u64)(est_rec / (double)nb1) / SK2_RCAP + 1;
+            const u64 exp_tiles = (u64)(est_rec / (double)nb1) / SK2Q_RCAP + 1;
             const unsigned blocks_per_sub = (unsigned)std::min<u64>(std::max<u64>(exp_tiles / 4, 1), 64);
-            if (getenv("PB_PART2_GENERIC")) sk_part2_kernel<SkStore12><<<dim3(blocks_per_sub, (unsigned)nb1), SK_THREADS, 0, ctx->stream>>>(p);   // development / A-B
-            else sk_part2_raw12_kernel<SkStore12><<<dim3(blocks_per_sub, (unsigned)nb1), SK_THREADS, 0, ctx->stream>>>(p);
+            sk_part2_raw16_kernel<<<dim3(blocks_per_sub, (unsigned)nb1), SK_THREADS, 0, ctx->stream>>>(p);
             t2.stop();
             LazyTimer t3(ctx, "bucket", 2);
-            sk_bucket_kernel<<<grid_for(nb2, 1, 256 * 16), SK_ROLL_THREADS, 0, ctx->stream>>>(p, (u64 *)ctx->dist_keys.p, (u32 *)ctx->dist_counts.p, out_cap);
+            if (k == 32) sk_bucket_kernel<32><<<grid_for(nb2, 1, 256 * 16), SK_ROLL_THREADS, 0, ctx->stream>>>(p, (u64 *)ctx->dist_keys.p, (u32 *)ctx->dist_counts.p, out_cap);
+            else sk_bucket_kernel<0><<<grid_for(nb2, 1, 256 * 16), SK_ROLL_THREADS, 0, ctx->stream>>>(p, (u64 *)ctx->dist_keys.p, (u32 *)ctx->dist_counts.p, out_cap);
             t3.stop();
             HIPCHK(hipGetLastError());
             HIPCHK(hipMemcpyAsync(sc, ctx->d_scalars.p, 72, hipMemcpyDeviceToHost, ctx->stream));
@@ -639,6 +650,20 @@ static int count_superk(pb_ctx *ctx, unsigned k, bool *done)
             HIPCHK(hipMemcpyAsync(ctx->h_hist, ctx->d_hist.p, 65536 * 8, hipMemcpyDeviceToHost, ctx->stream));   // final unless buckets were flagged
             HIPCHK(hipStreamSynchronize(ctx->stream));
             t1.read(); t2.read(); t3.read(); ti.read();
+        }
+        if (ctx->opt_verbose)
+            fprintf(stderr, "[pbgpu] super-k-mer pass: k %u, 2^%u buckets (l1 %u), cap1 %llu cap2 %u: windows %llu, records %llu, distinct %llu, flagged buckets %llu, "
+                            "spilled records %llu, overflow %llu\n", k, B, p.l1, (unsigned long long)p.cap1, p.cap2, (unsigned long long)sc[0], (unsigned long long)sc[6],
+                    (unsigned long long)sc[4], (unsigned long long)sc[7], (unsigned long long)sc[8], (unsigned long long)sc[1]);
+        if (ctx->opt_verbose && sc[7]) {
+            std::vector<u32> fl(nb2), cu(nb2);
+            (void)hipMemcpy(fl.data(), p.flag2, nb2 * 4, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(cu.data(), p.cursor2, nb2 * 4, hipMemcpyDeviceToHost);
+            std::map<u32, std::pair<u64, u64>> by;
+            u64 mx = 0;
+            for (u64 i = 0; i < nb2; ++i) { by[fl[i]].first++; by[fl[i]].second += cu[i]; mx = std::max<u64>(mx, cu[i]); }
+            for (auto &kv : by) fprintf(stderr, "[pbgpu]   flag %u: %llu buckets, %llu records\n", kv.first, (unsigned long long)kv.second.first, (unsigned long long)kv.second.second);
+            fprintf(stderr, "[pbgpu]   largest bucket %llu records\n", (unsigned long long)mx);
         }
         // sc[7] buckets had more distinct keys than an LDS table holds.  Many of them: the input is not the high-coverage kind
         // the bucket count was chosen for -- repeat with 4x the buckets rather than push a large share through the global table.
@@ -700,9 +725,9 @@ int pb_count(pb_ctx *ctx, unsigned k, uint64_t *occ_hist, uint64_t *max_occ, uin
     int rc;
     if ((rc = ensure(ctx, ctx->d_scalars, 16 * 8)) != PB_OK) return rc;
     bool done = false;
-    const char *force = getenv("PB_COUNT_PATH");       // "direct" | "superk" (development / A-B runs, tests on small inputs)
+    // small inputs take the direct pass unless pb_set_option("count_path") says otherwise
     const bool want_sk = ctx->W == 1 && ctx->stream_len >= k &&
-                         (force ? strcmp(force, "superk") == 0 || strcmp(force, "partitioned") == 0 : ctx->stream_len >= (1ull << 22));
+                         (ctx->opt_count_path ? ctx->opt_count_path == 2 : ctx->stream_len >= (1ull << 22));
     ctx->sk_records = 0;
     if (want_sk) {
         if ((rc = count_superk(ctx, k, &done)) != PB_OK) return rc;
@@ -953,8 +978,6 @@ static int merge_records_lds_impl(pb_ctx *ctx, const void *dev_keys, const void 
     int rc;
     *done = false;
     SkParams p;
-    p.abl = 0;
-    p.k = ctx->k; p.m = 0; p.w = 0; p.L = 0;
     p.B = B;
     p.l1 = B / 2;
     p.l2 = B - p.l1;
@@ -1008,7 +1031,7 @@ static int merge_records_lds(pb_ctx *ctx, const void *dev_keys, const void *dev_
     while (((u64)1536 << B) < n && B < 20) ++B;            // hash-uniform buckets: mean <= 1536 distinct keys, the table takes 3840
     if (((u64)1536 << B) < n) return PB_OK;
     int rc;
-    if (B <= 16 && !getenv("PB_MERGE_16B")) {              // records of the exchange carry 16-bit counts: 12 bytes per record do
+    if (B <= 16 && !ctx->opt_merge_16b) {              // records of the exchange carry 16-bit counts: 12 bytes per record do
         if ((rc = merge_records_lds_impl<SkStoreM12>(ctx, dev_keys, dev_counts, n, B, done)) != PB_OK || *done) return rc;
     }
     return merge_records_lds_impl<SkStore16>(ctx, dev_keys, dev_counts, n, B, done);
@@ -1026,7 +1049,7 @@ int pb_merge_records(pb_ctx *ctx, unsigned k, const void *dev_keys, const void *
     ctx->W = (int)((k + 31) / 32);
     if ((rc = ensure(ctx, ctx->d_scalars, 16 * 8)) != PB_OK) return rc;
     bool done = false;
-    if (ctx->W == 1 && !getenv("PB_MERGE_TABLE")) {
+    if (ctx->W == 1 && !ctx->opt_merge_table) {
         if ((rc = merge_records_lds(ctx, dev_keys, dev_counts, n, &done)) != PB_OK) return rc;
     }
     if (done) {

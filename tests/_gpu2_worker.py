@@ -25,6 +25,7 @@ def main():
     per = (n_pairs + world - 1) // world
     r1, r2 = synth.make_reads(genome, cov, seed, err=0.02, pair_lo=rank * per, pair_hi=min((rank + 1) * per, n_pairs))
     g = GpuCounter(0)
+    g.set_option("count_path", 2)       # the super-k-mer pass also on this small input
     g.reads_append_matrix(r1)
     g.reads_append_matrix(r2)
     g.make_kmer_read_distribution(k)

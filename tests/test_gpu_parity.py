@@ -9,6 +9,10 @@ from conftest import GOLDEN, case_reads
 
 pytestmark = pytest.mark.gpu
 
+from platanus_b_amd.binding import GpuCounter  # noqa: E402
+
+COUNT_PATH = {"auto": 0, "direct": 1, "superk": 2}      # pb_set_option("count_path")
+
 
 @pytest.fixture(scope="module")
 def gpu():
@@ -133,7 +137,7 @@ def test_longest_read_the_reference_accepts(gpu, oracle_built, monkeypatch):
     ohist, omax = oc.occ_hist()
     ok, ocn = oc.retain(1)
     for path in ("direct", "superk"):
-        monkeypatch.setenv("PB_COUNT_PATH", path)
+        monkeypatch.setitem(GpuCounter.default_options, "count_path", COUNT_PATH[path])
         g = gpu(0)
         g.reads_append(codes, off)
         hist = g.make_kmer_read_distribution(32)
@@ -244,7 +248,7 @@ def test_config2_full_size_through_the_cabi(gpu, manifest, tmp_path, monkeypatch
     krc, crc = grc.fetch_retained()
     assert np.array_equal(keys, krc) and np.array_equal(counts, crc)
     del grc
-    monkeypatch.setenv("PB_COUNT_PATH", "direct")
+    g.set_option("count_path", COUNT_PATH["direct"])
     hd = g.make_kmer_read_distribution(32)
     assert g.kernel_ms("part1") == 0
     assert np.array_equal(h, hd)
@@ -413,7 +417,7 @@ def test_low_coverage_mostly_distinct_kmers(gpu, oracle_built, monkeypatch):
     oc = _oracle(codes, off, 31, oracle_built)
     ohist, omax = oc.occ_hist()
     for path in ("superk", "direct"):
-        monkeypatch.setenv("PB_COUNT_PATH", path)
+        monkeypatch.setitem(GpuCounter.default_options, "count_path", COUNT_PATH[path])
         g = gpu(0)
         g.reads_append_matrix(codes)
         hist = g.make_kmer_read_distribution(31)
@@ -447,7 +451,7 @@ def test_superkmer_count_path_matches_oracle(k, gpu, oracle_built, monkeypatch):
     With k = 1 or 2 a handful of minimizers carry the whole input: the pass notices (spill list full) and hands over to the
     direct path, which must give the same answer."""
     from platanus_b_amd import synth
-    monkeypatch.setenv("PB_COUNT_PATH", "superk")
+    monkeypatch.setitem(GpuCounter.default_options, "count_path", COUNT_PATH["superk"])
     r1, r2 = synth.make_reads(60_000, 40, seed=140 + k, n_rate=0.002)
     _superk_case(gpu, oracle_built, np.concatenate([r1, r2]), k, must_take_path=k >= 9)
 
@@ -457,34 +461,37 @@ def test_superkmer_other_bucket_counts(bits, gpu, oracle_built, monkeypatch):
     """4 .. 2^18 minimizer buckets: 4 buckets overflow their LDS tables and go through the global table, 2^18 is what a
     3 G-window shard would use (longest records shrink to 21 windows)."""
     from platanus_b_amd import synth
-    monkeypatch.setenv("PB_COUNT_PATH", "superk")
-    monkeypatch.setenv("PB_FORCE_SKB", str(bits))
+    monkeypatch.setitem(GpuCounter.default_options, "count_path", COUNT_PATH["superk"])
+    monkeypatch.setitem(GpuCounter.default_options, "sk_bucket_bits", bits)
     r1, r2 = synth.make_reads(50_000, 50, seed=160 + bits, n_rate=0.001)
     _superk_case(gpu, oracle_built, np.concatenate([r1, r2]), 32, cutoffs=(1,))
 
 
 def test_superkmer_heavy_hitter_and_low_complexity(gpu, oracle_built, monkeypatch):
-    """Poly-A reads (one minimizer for the whole read, one 32-mer with 357000 instances) and dinucleotide repeats:
-    runs are cut every L positions, the bucket overflows its record capacity, results must not change."""
+    """Poly-A reads (every m-mer of a window ties for the minimum, so runs are 1 to 20 windows long and all land in one bucket, which
+    overflows its record capacity: spill list + flagged bucket through the global table; one 32-mer with 59500 instances) and
+    dinucleotide repeats; results must not change.  With seven times the poly-A reads the spill list overflows too and the pass
+    hands the input to the direct path: same results."""
     from platanus_b_amd import synth
-    monkeypatch.setenv("PB_COUNT_PATH", "superk")
+    monkeypatch.setitem(GpuCounter.default_options, "count_path", COUNT_PATH["superk"])
     r1, r2 = synth.make_reads(20_000, 30, seed=177)
-    poly = np.zeros((3000, 150), dtype=np.uint8)
-    di = np.tile(np.array([1, 2], dtype=np.uint8), (500, 75))
-    _superk_case(gpu, oracle_built, np.concatenate([r1, poly, di, r2]), 32, cutoffs=(2,))
+    di = np.tile(np.array([1, 2], dtype=np.uint8), (250, 75))
+    for n_poly, must in ((500, True), (3600, False)):
+        poly = np.zeros((n_poly, 150), dtype=np.uint8)
+        _superk_case(gpu, oracle_built, np.concatenate([r1, poly, di, r2]), 32, cutoffs=(2,), must_take_path=must)
 
 
 def test_superkmer_low_coverage_mostly_distinct(gpu, oracle_built, monkeypatch):
     """2x coverage, 2 % errors: nearly every instance is a distinct key, far more than the LDS tables are sized for."""
     from platanus_b_amd import synth
-    monkeypatch.setenv("PB_COUNT_PATH", "superk")
+    monkeypatch.setitem(GpuCounter.default_options, "count_path", COUNT_PATH["superk"])
     r1, r2 = synth.make_reads(300_000, 2, seed=191, err=0.02)
     _superk_case(gpu, oracle_built, np.concatenate([r1, r2]), 31, cutoffs=(1,))
 
 
 def test_merge_records_through_lds_tables(gpu, oracle_built, monkeypatch):
     """pb_merge_records on > 1 M records takes the partition + LDS-table path (stage "merge" of the counting machinery); the
-    result must equal both the oracle and the global-table path (PB_MERGE_TABLE=1).  Input: every distinct k-mer of a 2 %-error
+    result must equal both the oracle and the global-table path (pb_set_option "merge_table").  Input: every distinct k-mer of a 2 %-error
     read set split into two records whose counts add up, plus a heavy hitter that arrives as 3000 records."""
     import ctypes as C
     import torch
@@ -516,7 +523,7 @@ def test_merge_records_through_lds_tables(gpu, oracle_built, monkeypatch):
     expect = np.minimum(ocn.astype(np.int64) + np.where(ok.reshape(-1) == keys[hot], 60000, 0), 65534).astype(np.uint16)
     for table_path in (False, True):
         if table_path:
-            monkeypatch.setenv("PB_MERGE_TABLE", "1")
+            g.set_option("merge_table", 1)
         hist = np.zeros(65535, dtype=np.uint64)
         mx, nd = C.c_uint64(), C.c_uint64()
         torch.cuda.synchronize()
@@ -539,7 +546,7 @@ def test_two_ranks_share_one_gpu(world, port, oracle_built, tmp_path):
     from platanus_b_amd import synth
     k, genome, cov, seed = 31, 300_000, 40.0, 33
     out = tmp_path / "res.json"
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", PB_COUNT_PATH="superk")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "tests", "_gpu2_worker.py"), str(k), str(genome), str(cov), str(seed), str(out)]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
@@ -563,7 +570,7 @@ def test_two_ranks_share_one_gpu(world, port, oracle_built, tmp_path):
 def test_superkmer_ragged_reads(gpu, oracle_built, monkeypatch):
     """Reads of very different lengths in one stream: empty, shorter than k, exactly k, 150 bp, 20 kbp (longer than a kernel
     tile, so its runs cross tile and lane boundaries), with N runs -- the super-k-mer path against the oracle."""
-    monkeypatch.setenv("PB_COUNT_PATH", "superk")
+    monkeypatch.setitem(GpuCounter.default_options, "count_path", COUNT_PATH["superk"])
     rng = np.random.default_rng(77)
     genome = rng.integers(0, 4, 60_000).astype(np.uint8)
     reads = []

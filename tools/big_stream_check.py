@@ -30,7 +30,7 @@ def main():
     print(f"{n_reads} reads, {n_bases} bases (2^32 = {1 << 32})", flush=True)
     res = {}
     for path in ("superk", "direct"):
-        os.environ["PB_COUNT_PATH"] = path
+        g.set_option("count_path", 1 if path == "direct" else 2)
         t0 = time.time()
         h = g.make_kmer_read_distribution(32).copy()
         dt = time.time() - t0
@@ -42,7 +42,7 @@ def main():
         keys, counts = g.fetch_retained()
         assert (keys[1:, 0] > keys[:-1, 0]).all()
         res[path] = (h, keys, counts)
-        print(f"PB_COUNT_PATH={path}: took the {took} pass, {dt * 1e3:.0f} ms wall, kernels {g.kernel_ms('count'):.1f} ms, "
+        print(f"count_path={path}: took the {took} pass, {dt * 1e3:.0f} ms wall, kernels {g.kernel_ms('count'):.1f} ms, "
               f"{g.n_instances} windows, {g.n_distinct} distinct, {n} retained (>= 3), bucket bits {g.kernel_ms('sk_bucket_bits'):.0f}, "
               f"flagged {g.kernel_ms('sk_flagged_buckets'):.0f}", flush=True)
     assert np.array_equal(res["superk"][0], res["direct"][0])

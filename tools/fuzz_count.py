@@ -46,10 +46,10 @@ def main():
         skb = str(int(rng.integers(2, 19))) if rng.random() < 0.5 else None
 
         def run(path):
-            os.environ["PB_COUNT_PATH"] = path
-            if path == "superk" and skb:
-                os.environ["PB_FORCE_SKB"] = skb
             g = GpuCounter(0)
+            g.set_option("count_path", 1 if path == "direct" else 2)
+            if path == "superk" and skb:
+                g.set_option("sk_bucket_bits", int(skb))
             g.reads_append(codes, off)
             hist = g.make_kmer_read_distribution(k)
             took = g.kernel_ms("part1") > 0
@@ -57,7 +57,6 @@ def main():
             keys, counts = g.fetch_retained()
             out = (hist.copy(), keys.copy(), counts.copy(), g.n_instances, took)
             g.close()
-            os.environ.pop("PB_FORCE_SKB", None)
             return out
 
         for path in ("direct", "superk"):
@@ -80,7 +79,6 @@ def main():
             print(f"MISMATCH case {case}: G={G} cov={cov} err={err} n={n_rate} k={k} reads={len(reads)} instances {d[3]} vs {s_[3]} distinct {len(d[1])} vs {len(s_[1])}", flush=True)
         elif case % 10 == 0:
             print(f"case {case}: ok (G={G} cov={cov} k={k} reads={len(reads)} instances={d[3]} distinct={len(d[1])} superk={s_[4]})", flush=True)
-    os.environ.pop("PB_COUNT_PATH", None)
     print(f"{n_cases} cases, {bad} mismatches")
     sys.exit(1 if bad else 0)
 

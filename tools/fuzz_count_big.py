@@ -57,14 +57,13 @@ def main():
             total += m * L
         res = {}
         for path in ("superk", "direct"):
-            os.environ["PB_COUNT_PATH"] = path
+            g.set_option("count_path", 1 if path == "direct" else 2)
             h = g.make_kmer_read_distribution(k).copy()
             took = g.kernel_ms("part1") > 0
             stats = (int(g.kernel_ms("sk_bucket_bits")), int(g.kernel_ms("sk_flagged_buckets")), int(g.kernel_ms("sk_spilled_records"))) if took else None
             g.retain(1)
             keys, counts = g.fetch_retained()
             res[path] = (h, keys, counts, g.n_instances, took, stats)
-        os.environ.pop("PB_COUNT_PATH", None)
         a, b = res["superk"], res["direct"]
         ok = a[3] == b[3] and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
         bad += not ok

@@ -1,5 +1,5 @@
 """Development aid: differential test of pb_merge_records -- the partition + LDS-table merge of (key,count) records against the
-global-table merge (PB_MERGE_TABLE=1) on random record lists: duplicates, zero counts, heavy hitters, k = 1..32.
+global-table merge (pb_set_option "merge_table") on random record lists: duplicates, zero counts, heavy hitters, k = 1..32.
 usage: python tools/fuzz_merge.py [n_cases] [seed]"""
 import ctypes as C
 import os
@@ -38,11 +38,8 @@ def main():
         tc = torch.from_numpy(rc.astype(np.int32)).cuda()
         res = []
         for table in (False, True):
-            if table:
-                os.environ["PB_MERGE_TABLE"] = "1"
-            else:
-                os.environ.pop("PB_MERGE_TABLE", None)
             g = GpuCounter(0)
+            g.set_option("merge_table", 1 if table else 0)
             hist = np.zeros(65535, dtype=np.uint64)
             mx, nd = C.c_uint64(), C.c_uint64()
             torch.cuda.synchronize()
@@ -53,7 +50,6 @@ def main():
             gk, gc = g.fetch_retained()
             res.append((hist.copy(), gk.copy(), gc.copy(), nd.value, used_lds))
             g.close()
-        os.environ.pop("PB_MERGE_TABLE", None)
         a, b = res
         ok = np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[3] == b[3]
         if not ok:
