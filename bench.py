@@ -12,9 +12,11 @@ ends with the owner exchange of (key,count) records over RCCL (torch.distributed
 merge + all-reduce of the histogram.
 
 Reads are packed on the device before the timed region (inputs resident in HBM).  The JSON line carries
-`roofline` (HBM, algorithmic bytes 12.25 B per k-mer instance at k=32: SURVEY.md 8(d)) and `cpu_baseline`
-(the real reference binary oracle/_ref/platanus_b on a bounded sample, counting stage only, timed from its
-own progress lines; falls back to the repo's CPU port when the binary did not travel).
+`roofline` (HBM, algorithmic bytes 12.25 B per k-mer instance at k=32: SURVEY.md 8(d)), `cpu_baseline`
+(the real reference binary oracle/_ref/platanus_b on the bench workload itself, counting stage only, timed
+from its own progress lines; falls back to the repo's CPU port when the binary did not travel),
+`end_to_end` (the drop-in CLI on the same FASTQ files, outputs checked against the reference's md5s) and
+`shard_shapes` (the counting pass on what one of the 8 GPUs of configs[3] and configs[4] holds).
 """
 import argparse
 import json
@@ -37,96 +39,122 @@ K = 32
 SEED = 1
 BYTES_PER_INSTANCE = 0.25 + 8 * ((K + 31) // 32) + 4        # 12.25 B at k = 32
 HBM_PEAK_GBS = 8000.0                                        # MI355X_MICROARCH.md: 8 TB/s spec
+TRAFFIC_PROFILE = "r02_hbm_traffic_superk.json"              # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (tools/pmc_traffic.py)
 
 
-def cpu_baseline(sample_cov=20.0, threads=None):
-    """Counting-stage rate of the CPU reference on a bounded sample of the same workload (rank 0, N=1 only)."""
+def _sha1(path):
+    import hashlib
+    return hashlib.sha1(open(path, "rb").read()).hexdigest()
+
+
+def _write_workload(tmp):
+    """The bench workload as the two FASTQ files a user would have (same generator, same seed as the resident reads)."""
     from platanus_b_amd import synth
+    synth.write_pair_files(os.path.join(tmp, "in"), GENOME, COVERAGE, SEED)
+    return os.path.join(tmp, "in_1.fq"), os.path.join(tmp, "in_2.fq")
+
+
+def cpu_baseline(tmp, f1, f2):
+    """Counting-stage rate of the CPU reference on the bench workload itself (rank 0, N=1 only): the real reference binary
+    (oracle/_ref/platanus_b, built from /root/reference by oracle/Makefile) with its defaults -m 16 and all host threads it can use
+    (-t min(8, cores): the reference's counting does not scale beyond that), timed between its own progress
+    lines around makeKmerReadDistributionMT (assemble.cpp:306,334); the run is stopped there."""
     from oracle import pyoracle
     ncpu = os.cpu_count() or 1
-    threads = threads or min(8, ncpu)
-    # same genome as the GPU workload (same table pressure from genomic k-mers), one fifth of its coverage
-    n_pairs = int(GENOME * sample_cov) // (2 * READ_LEN)
+    threads = min(8, ncpu)
+    n_pairs = int(GENOME * COVERAGE) // (2 * READ_LEN)
     instances = 2 * n_pairs * (READ_LEN - K + 1)
-    sample = f"{GENOME / 1e6:g} Mbp x {sample_cov:.0f}x PE{READ_LEN} seed {SEED} ({2 * n_pairs} reads, {instances} {K}-mers), counting stage only"
+    sample = f"the bench workload: {GENOME / 1e6:g} Mbp x {COVERAGE:.0f}x PE{READ_LEN} seed {SEED} ({2 * n_pairs} reads, {instances} {K}-mers), counting stage only"
     if pyoracle.have_reference():
-        tmp = tempfile.mkdtemp(prefix="pb_cpu_")
-        try:
-            synth.write_pair_files(os.path.join(tmp, "s"), GENOME, sample_cov, SEED)
-            cmd = [pyoracle.REF_BIN, "assemble", "-k", str(K), "-t", str(threads), "-m", "16", "-kmer_occ_only", "-tmp", tmp,
-                   "-o", os.path.join(tmp, "o"), "-f", os.path.join(tmp, "s_1.fq"), os.path.join(tmp, "s_2.fq")]
-            p = subprocess.Popen(cmd, stderr=subprocess.PIPE, stdout=subprocess.DEVNULL, text=True)
-            t0 = t1 = None
-            for line in p.stderr:          # makeKmerReadDistributionMT runs between these two progress lines
-                if line.startswith("K = ") and "saving kmers from reads" in line:
-                    t0 = time.perf_counter()      # assemble.cpp:306
-                elif line.startswith("AVE_READ_LEN="):
-                    t1 = time.perf_counter()      # assemble.cpp:334
-                    break
-            p.kill()
-            p.wait()
-            # the device build of the same CLI on the same sample files: end-to-end wall time of the full multi-k assemble
-            # (FASTQ parse + upload + every k round + FASTA write); reported next to the baseline, not part of `value`
-            gpu_cli = os.path.join(ROOT, "platanus_b_amd", "bin", "platanus_b")
-            extra = None
-            if os.path.exists(gpu_cli):
-                g0 = time.perf_counter()
-                r = subprocess.run([gpu_cli, "assemble", "-k", str(K), "-o", os.path.join(tmp, "g"), "-f", os.path.join(tmp, "s_1.fq"),
-                                    os.path.join(tmp, "s_2.fq")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-                if r.returncode == 0:
-                    extra = {"wall_s": time.perf_counter() - g0, "what": "platanus_b_amd/bin/platanus_b assemble -k 32 (full multi-k, FASTQ in, "
-                             "contig.fa out) on the cpu_baseline sample files"}
-            if t0 is not None and t1 is not None:
-                out = {"value": instances / (t1 - t0), "unit": "k-mers/s", "cores": threads, "kind": "reference",
-                       "sample": sample + f", -t {threads} -m 16 (reference defaults), {t1 - t0:.1f} s"}
-                if extra:
-                    out["gpu_assemble_same_sample"] = extra
-                return out
-        finally:
-            subprocess.run(["rm", "-rf", tmp])
-    # CPU port (oracle restatement, single thread)
-    r1, r2 = synth.make_reads(GENOME, sample_cov / 4, SEED)
+        cmd = [pyoracle.REF_BIN, "assemble", "-k", str(K), "-t", str(threads), "-m", "16", "-kmer_occ_only", "-tmp", tmp, "-o", os.path.join(tmp, "ref"), "-f", f1, f2]
+        p = subprocess.Popen(cmd, stderr=subprocess.PIPE, stdout=subprocess.DEVNULL, text=True)
+        t0 = t1 = None
+        for line in p.stderr:          # makeKmerReadDistributionMT runs between these two progress lines
+            if line.startswith("K = ") and "saving kmers from reads" in line:
+                t0 = time.perf_counter()      # assemble.cpp:306
+            elif line.startswith("AVE_READ_LEN="):
+                t1 = time.perf_counter()      # assemble.cpp:334
+                break
+        p.kill()
+        p.wait()
+        if t0 is not None and t1 is not None:
+            return {"value": instances / (t1 - t0), "unit": "k-mers/s", "cores": ncpu, "threads": threads, "kind": "reference",
+                    "sample": sample + f", -t {threads} -m 16 (reference defaults), {t1 - t0:.1f} s"}
+    # CPU port (oracle restatement, single thread) on a fifth of the coverage: the binary did not travel
+    from platanus_b_amd import synth
+    r1, r2 = synth.make_reads(GENOME, COVERAGE / 20, SEED)
     codes = np.concatenate([r1, r2])
     n, L = codes.shape
     oc = pyoracle.OracleCounter()
     t0 = time.perf_counter()
     oc.count(codes.reshape(-1), np.arange(n + 1, dtype=np.uint64) * np.uint64(L), K, 4 * 10 ** 9)
     dt = time.perf_counter() - t0
-    return {"value": n * (L - K + 1) / dt, "unit": "k-mers/s", "cores": 1, "kind": "port",
-            "sample": f"{GENOME / 1e6:g} Mbp x {sample_cov / 4:.0f}x PE{READ_LEN} seed {SEED}, oracle/ restatement -t 1, {dt:.1f} s"}
+    return {"value": n * (L - K + 1) / dt, "unit": "k-mers/s", "cores": ncpu, "threads": 1, "kind": "port",
+            "sample": f"{GENOME / 1e6:g} Mbp x {COVERAGE / 20:.0f}x PE{READ_LEN} seed {SEED}, oracle/ restatement -t 1, {dt:.1f} s"}
 
 
-def end_to_end():
+def end_to_end(tmp, f1, f2):
     """BASELINE.json's second metric: wall time of the drop-in CLI on the bench workload (FASTQ files in, files out, process start to
-    exit): `assemble -kmer_occ_only` (configs[1]) and the full multi-k `assemble` (configs[2]); the outputs of the latter are compared
-    with the md5 of the real reference's files for this input (tests/golden/manifest.json, cfg3)."""
+    exit): `assemble -kmer_occ_only` (configs[1]) and the full multi-k `assemble` (configs[2]); the outputs are compared with the md5
+    of the real reference's files for this input (tests/golden/manifest.json, cfg3: contigs, histogram and PREFIX_kmer_occ.bin)."""
     import hashlib
-    from platanus_b_amd import synth
     cli = os.path.join(ROOT, "platanus_b_amd", "bin", "platanus_b")
     if not os.path.exists(cli):
         return None
-    tmp = tempfile.mkdtemp(prefix="pb_e2e_")
-    try:
-        synth.write_pair_files(os.path.join(tmp, "in"), GENOME, COVERAGE, SEED)
-        out = {"input": f"{GENOME / 1e6:g} Mbp x {COVERAGE:.0f}x PE{READ_LEN} seed {SEED}, two FASTQ files in the page cache", "runs": 2}
-        for name, extra in (("assemble_kmer_occ_only_wall_s", ["-kmer_occ_only"]), ("assemble_full_multik_wall_s", [])):
-            best = None
-            for _ in range(2):
-                t0 = time.perf_counter()
-                r = subprocess.run([cli, "assemble", "-k", str(K), *extra, "-o", os.path.join(tmp, "o"), "-f", os.path.join(tmp, "in_1.fq"),
-                                    os.path.join(tmp, "in_2.fq")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-                dt = time.perf_counter() - t0
-                if r.returncode != 0:
-                    return {"error": f"{name}: exit status {r.returncode}"}
-                best = dt if best is None else min(best, dt)
-            out[name] = best
-        man = json.load(open(os.path.join(ROOT, "tests", "golden", "manifest.json")))["cfg3"]["runs"]["multik"]["files"]
-        md5 = {fn: hashlib.md5(open(os.path.join(tmp, fn.replace("out_", "o_", 1)), "rb").read()).hexdigest() for fn in man}
-        out["outputs_identical_to_reference_md5"] = all(md5[fn] == man[fn]["md5"] for fn in man)
-        out["reference_wall_s"] = {"assemble_full_multik": 1098, "where": "build container, 8 cores, -t 8 (tests/golden/manifest.json)"}
-        return out
-    finally:
-        subprocess.run(["rm", "-rf", tmp])
+    out = {"input": f"{GENOME / 1e6:g} Mbp x {COVERAGE:.0f}x PE{READ_LEN} seed {SEED}, two FASTQ files in the page cache", "runs": 2}
+    for name, extra in (("assemble_kmer_occ_only_wall_s", ["-kmer_occ_only"]), ("assemble_full_multik_wall_s", [])):
+        best = None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            r = subprocess.run([cli, "assemble", "-k", str(K), *extra, "-o", os.path.join(tmp, "o"), "-f", f1, f2], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            dt = time.perf_counter() - t0
+            if r.returncode != 0:
+                return {"error": f"{name}: exit status {r.returncode}"}
+            best = dt if best is None else min(best, dt)
+        out[name] = best
+    runs = json.load(open(os.path.join(ROOT, "tests", "golden", "manifest.json")))["cfg3"]["runs"]
+    man = runs["multik"]["files"]
+    md5 = {fn: hashlib.md5(open(os.path.join(tmp, fn.replace("out_", "o_", 1)), "rb").read()).hexdigest() for fn in man}
+    out["outputs_identical_to_reference_md5"] = all(md5[fn] == man[fn]["md5"] for fn in man)
+    # configs[1]'s own artefact: PREFIX_kmer_occ.bin of the -kmer_occ_only run above (defaults = -t 1 -m 16) against the reference's md5
+    occ = runs["occ_t1"]["files"]["out_kmer_occ.bin"]
+    out["kmer_occ_bin_identical_to_reference_md5"] = hashlib.md5(open(os.path.join(tmp, "o_kmer_occ.bin"), "rb").read()).hexdigest() == occ["md5"]
+    out["reference_wall_s"] = {"assemble_full_multik": 1098, "assemble_kmer_occ_only_t1": 234,
+                               "where": "build container, 8 cores (tests/golden/manifest.json)"}
+    return out
+
+
+def shard_shapes():
+    """BASELINE configs[3] and [4] at the shape ONE of their 8 GPUs sees (counting pass only, this GPU): the 1/8 read range of
+    5 Mbp x 1000x and of 100 Mbp x 100x (12.5x of a 100 Mbp genome: the mostly-distinct regime before the merge).  Checked through
+    size-independent properties: sum(hist) = distinct, sum(i * hist) = windows."""
+    from platanus_b_amd import synth
+    from platanus_b_amd.binding import GpuCounter
+    out = {}
+    for name, genome_bp, cov, seed in (("configs[3] shard: 5 Mbp x 1000x / 8", 5_000_000, 1000.0, SEED), ("configs[4] shard: 100 Mbp x 100x / 8", 100_000_000, 100.0, 5)):
+        g = GpuCounter(0)
+        genome = synth.make_genome(genome_bp, seed)
+        n_pairs = int(genome_bp * cov) // (2 * READ_LEN) // 8
+        for lo in range(0, n_pairs, 250_000):
+            r1, r2 = synth.make_reads(genome_bp, cov, seed, genome=genome, pair_lo=lo, pair_hi=min(lo + 250_000, n_pairs))
+            g.reads_append_matrix(r1)
+            g.reads_append_matrix(r2)
+        ms = []
+        for it in range(4):
+            h = g.make_kmer_read_distribution(K)
+            if it:
+                ms.append(g.kernel_ms("count"))
+        idx = np.arange(len(h), dtype=np.uint64)
+        ok = int(h.sum()) == g.n_distinct and int((idx * h).sum()) == g.n_instances and g.n_instances == 2 * n_pairs * (READ_LEN - K + 1)
+        k_ms = float(np.mean(ms))
+        out[name] = {"reads": 2 * n_pairs, "kmer_instances": int(g.n_instances), "distinct_kmers": int(g.n_distinct), "kernel_ms": k_ms,
+                     "kmers_per_s": g.n_instances / (k_ms * 1e-3), "roofline_frac": g.n_instances * BYTES_PER_INSTANCE / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "super_kmer_pass": g.kernel_ms("part1") > 0, "bucket_bits": int(g.kernel_ms("sk_bucket_bits")),
+                     "flagged_buckets": int(g.kernel_ms("sk_flagged_buckets")), "spilled_records": int(g.kernel_ms("sk_spilled_records")),
+                     "identities_hold": bool(ok)}
+        g.close()
+        del g, genome
+    return out
 
 
 def main():
@@ -135,7 +163,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--genome", type=int, default=GENOME, help="override the workload size (development only)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline, the end-to-end CLI runs and the shard shapes (profiling runs)")
     a = ap.parse_args()
 
     import torch
@@ -224,15 +252,26 @@ def main():
         achieved = instances * BYTES_PER_INSTANCE / (k_ms * 1e-3) / 1e9
         parts = {st: float(np.mean(v)) for st, v in stage_ms.items()}
         partitioned = parts["part1"] > 0
-        kernel = ("sk_part1_kernel + sk_part2_raw12_kernel + sk_bucket_kernel + sk_flagged_kernel (super-k-mer counting pass)"
+        kernel = ("sk_part1_kernel + sk_part2_raw16_kernel + sk_bucket_kernel + sk_flagged_kernel (super-k-mer counting pass)"
                   if partitioned else "count_kernel<1> (direct global-atomic counting pass)")
-        # HBM bytes per counting pass from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes
-        # of this same command, corrected as MI355X_MICROARCH.md prescribes): profiles/r01_hbm_traffic.json.  Only quoted
-        # when the run is the profiled workload and path.
-        traffic = None
-        tj = os.path.join(ROOT, "profiles", "r01_hbm_traffic_superk.json")
+        # HBM bytes per counting pass from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes of this same
+        # command, corrected as MI355X_MICROARCH.md prescribes).  NOT measured by this run: read from the committed profile, and only
+        # quoted when the run is the profiled workload and path and the profile is not older than the kernels it describes.
+        traffic = traffic_source = None
+        tj = os.path.join(ROOT, "profiles", TRAFFIC_PROFILE)
+        ksrc = os.path.join(ROOT, "platanus_b_amd", "csrc", "kernels_superk.inc")
         if partitioned and a.genome == GENOME and world == 1 and os.path.exists(tj):
-            traffic = json.load(open(tj)).get("hbm_bytes_per_counting_pass")
+            prof = json.load(open(tj))
+            if prof.get("kernels_sha1") == _sha1(ksrc):
+                traffic = prof.get("hbm_bytes_per_counting_pass")
+                traffic_source = {"file": "profiles/" + TRAFFIC_PROFILE, "kernels_sha1": prof.get("kernels_sha1"), "measured_by_this_run": False}
+        # the timed loop's own result: the occurrence distribution of the last step as the reference's TSV, against the reference's md5
+        hist_ok = None
+        if a.genome == GENOME and world == 1:
+            import hashlib
+            tsv = "".join(f"{i}\t{int(g.occ_hist[i])}\n" for i in range(1, g.max_occ + 1))
+            man = json.load(open(os.path.join(ROOT, "tests", "golden", "manifest.json")))["cfg3"]["runs"]["multik"]["files"]["out_32merFrq.tsv"]
+            hist_ok = hashlib.md5(tsv.encode()).hexdigest() == man["md5"]
         out = {
             "metric": "k-mers/sec", "value": total_instances * a.steps / dt, "unit": "k-mers/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
@@ -240,23 +279,36 @@ def main():
             "config": {"workload": f"{a.genome / 1e6:g} Mbp synthetic genome, {COVERAGE * world:.0f}x PE{READ_LEN}, k={K}, "
                                    f"occurrence table only (BASELINE configs[1] per GPU)",
                        "reads_per_gpu": int(n_reads), "kmer_instances_per_gpu": int(instances), "distinct_kmers": int(g.n_distinct),
-                       "parallelism": f"reads range-partitioned over {world} GPU(s)" + (", owner exchange over RCCL" if world > 1 else "")},
+                       "parallelism": f"reads range-partitioned over {world} GPU(s)" + (", owner exchange over RCCL" if world > 1 else ""),
+                       "torch_distributed": ({"backend": dist.get_backend(), "world_size": dist.get_world_size()} if dist is not None else None),
+                       "histogram_identical_to_reference_md5": hist_ok,
+                       "inherited_PB_environment": {k_: v for k_, v in os.environ.items() if k_.startswith("PB_")}},
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": k_ms, "measured_d2d_copy_GBs": copy_gbs,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "kernel_ms": k_ms, "measured_d2d_copy_GBs": copy_gbs,
                          "algorithmic_bytes_per_launch": instances * BYTES_PER_INSTANCE,
                          "kernels_ms": {"part1": parts["part1"], "part2": parts["part2"], "bucket_count": parts["bucket"],
                                         "flagged_buckets": parts["seg_compact"], "table_init": float(np.mean(init_ms)),
                                         "table_to_arrays": parts["compact"], "hist": float(np.mean(hist_ms))}},
         }
         if world == 1 and not a.no_cpu_baseline:
+            g.close()                        # the legs below bring their own contexts (and the reference needs the host's memory)
+            tmp = tempfile.mkdtemp(prefix="pb_bench_")
             try:
-                out["cpu_baseline"] = cpu_baseline()
-            except Exception as e:          # the baseline is a reported number, never a reason to lose the bench line
-                out["cpu_baseline"] = {"value": None, "unit": "k-mers/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+                f1, f2 = _write_workload(tmp)
+                try:
+                    out["cpu_baseline"] = cpu_baseline(tmp, f1, f2)
+                except Exception as e:          # the baseline is a reported number, never a reason to lose the bench line
+                    out["cpu_baseline"] = {"value": None, "unit": "k-mers/s", "cores": os.cpu_count() or 0, "threads": 0, "kind": "port", "sample": f"failed: {e}"}
+                try:
+                    out["end_to_end"] = end_to_end(tmp, f1, f2)
+                except Exception as e:
+                    out["end_to_end"] = {"error": str(e)}
+            finally:
+                subprocess.run(["rm", "-rf", tmp])
             try:
-                out["end_to_end"] = end_to_end()
+                out["shard_shapes"] = shard_shapes()
             except Exception as e:
-                out["end_to_end"] = {"error": str(e)}
+                out["shard_shapes"] = {"error": str(e)}
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

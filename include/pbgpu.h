@@ -118,6 +118,27 @@ int pb_merge_end(pb_ctx *ctx, uint64_t *occ_hist, uint64_t *max_occ, uint64_t *n
 int pb_merge_records(pb_ctx *ctx, unsigned k, const void *dev_keys, const void *dev_counts, uint64_t n, uint64_t *occ_hist,
                      uint64_t *max_occ, uint64_t *n_distinct);
 
+/* ---- E2: N ranks of one node on one run (configs 4 and 5: reads range-partitioned over the GPUs, one merged table for the graph
+ * stage and for every later round, assemble.cpp:343-354,449-478).  The launcher calls pb_dist_shared_create BEFORE it forks the ranks
+ * (no HIP call inside); every rank then makes its own context and attaches.  All pb_dist_* calls below are collective: every rank
+ * of the group must make them in the same order.
+ *   pb_dist_attach         use_rccl != 0: records travel device to device over RCCL/xGMI (one GPU per rank; librccl.so.1 is loaded
+ *                          on demand); 0: through shared host memory (ranks that share a GPU)
+ *   pb_dist_merge_counts   after pb_count on this rank's reads: owner exchange + merge; the context's table is then this rank's owner
+ *                          shard, the outputs describe the GLOBAL distribution (= pb_count's outputs of a single process on all reads)
+ *   pb_dist_gather_retained  after pb_retain on every shard: the union of all shards, sorted, becomes every rank's retained set
+ *   pb_dist_count_considering_contigs  pb_count_considering_contigs over all ranks' surviving reads (the contig table is replicated)
+ *   pb_dist_allreduce_u64  element-wise sum of a host array (read-length histogram, kept-read counts) */
+int pb_dist_shared_create(int world, void **shared);
+int pb_dist_attach(pb_ctx *ctx, void *shared, int rank, int world, int use_rccl);
+int pb_dist_detach(pb_ctx *ctx);
+int pb_dist_info(const pb_ctx *ctx, int *rank, int *world, int *rccl);
+int pb_dist_barrier(pb_ctx *ctx);
+int pb_dist_allreduce_u64(pb_ctx *ctx, uint64_t *buf, uint64_t n);
+int pb_dist_merge_counts(pb_ctx *ctx, uint64_t *occ_hist, uint64_t *max_occ, uint64_t *n_distinct);
+int pb_dist_count_considering_contigs(pb_ctx *ctx, unsigned k, uint64_t *occ_hist, uint64_t *max_occ, uint64_t *n_distinct);
+int pb_dist_gather_retained(pb_ctx *ctx, uint64_t *n_total);
+
 /* ---- graph stage: device part of BruijnGraph::makeInitialBruijnGraph (graph.h:289-579) ------------------------ */
 /* On the retained, sorted set of the last pb_retain (n keys).  For retained k-mer i in its canonical orientation:
  *   adj[i]      = (left flags << 4) | right flags; bit b of a nibble is set iff the predecessor / successor with

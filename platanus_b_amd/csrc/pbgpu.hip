@@ -97,6 +97,7 @@ struct pb_ctx {
     DevBuf table;
     u64 table_cap = 0;
     u64 n_instances = 0, n_distinct = 0;
+    u64 n_novel = 0;                    // pb_count_considering_contigs: leading records of the distinct arrays that came from reads
     DevBuf d_hist;                      // u64[65536]
     DevBuf d_scalars;                   // u64[16] scratch counters
 
@@ -153,6 +154,9 @@ struct pb_ctx {
     u64 layout_records = 0;
     u64 n_chains = 0, chain_seq_words = 0;
     void *chain_ptrs[2] = {nullptr, nullptr};
+
+    // N ranks on one run (dist.inc)
+    struct PbDist *dist = nullptr;
 
     // scratch
     DevBuf scratch[6];
@@ -277,11 +281,13 @@ int pb_create(int device_id, pb_ctx **out)
     return PB_OK;
 }
 
+extern "C" int pb_dist_detach(pb_ctx *ctx);
 void pb_destroy(pb_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->dev);
     (void)hipStreamSynchronize(ctx->stream);
+    (void)pb_dist_detach(ctx);
     release(ctx->packed); release(ctx->nmask); release(ctx->table); release(ctx->d_hist); release(ctx->d_scalars);
     release(ctx->ret_keys); release(ctx->ret_counts); release(ctx->exp_keys); release(ctx->exp_counts); release(ctx->merge_table);
     release(ctx->dist_keys); release(ctx->dist_counts); release(ctx->part_bucket1); release(ctx->part_bucket2); release(ctx->part_meta); release(ctx->part_spill);
@@ -711,6 +717,40 @@ static int count_superk(pb_ctx *ctx, unsigned k, bool *done)
     return PB_OK;
 }
 
+// scratch[2] (keys, n * W words) and scratch[3] (u32 counts) -> ctx->ret_keys / ret_counts, ascending by the 2k-bit key value
+// (counter.h:916-951 std::sort); the sorted set becomes the context's retained set
+static int sort_retained(pb_ctx *ctx, u64 n)
+{
+    int rc;
+    const int W = ctx->W;
+    DevBuf &ck = ctx->scratch[2], &cc = ctx->scratch[3];
+    ctx->n_retained = n;
+    if ((rc = ensure(ctx, ctx->ret_keys, std::max<u64>(n, 1) * W * 8)) != PB_OK) return rc;
+    if ((rc = ensure(ctx, ctx->ret_counts, std::max<u64>(n, 1) * 2)) != PB_OK) return rc;
+    if (n == 0) return PB_OK;
+    if (n >= (1ull << 32)) { ctx->err = "more than 2^32 retained k-mers on one GPU"; return PB_ERANGE; }
+    // LSD radix sort of a permutation, one key word at a time (least significant word first)
+    const u32 n_tiles = (u32)((n + RS_TILE - 1) / RS_TILE);
+    DevBuf &sk_a = ctx->scratch[4], &sk_b = ctx->scratch[5], &pv = ctx->scratch[0], &cn = ctx->scratch[1];
+    if ((rc = ensure(ctx, sk_a, n * 8)) != PB_OK) return rc;
+    if ((rc = ensure(ctx, sk_b, n * 8)) != PB_OK) return rc;
+    if ((rc = ensure(ctx, pv, n * 4 * 2)) != PB_OK) return rc;
+    if ((rc = ensure(ctx, cn, ((u64)256 * n_tiles + (u64)256 * n_tiles / RS_SCAN_CHUNK + 16) * 4)) != PB_OK) return rc;   // digit counts + scan block sums
+    u32 *perm_a = (u32 *)pv.p, *perm_b = perm_a + n;
+    StageTimer tm(ctx, "sort");
+    iota_kernel<<<grid_for(n, 256), 256, 0, ctx->stream>>>(perm_a, n);
+    const unsigned total_bits = 2 * ctx->k;
+    for (int w = 0; w < W; ++w) {
+        const unsigned bits = std::min<unsigned>(64u, total_bits - 64u * (unsigned)w);
+        gather_word_kernel<<<grid_for(n, 256), 256, 0, ctx->stream>>>((const u64 *)ck.p, perm_a, n, W, w, (u64 *)sk_a.p);
+        if ((rc = radix_sort_pairs(ctx, (u64 *)sk_a.p, perm_a, (u64 *)sk_b.p, perm_b, n, bits, (u32 *)cn.p, n_tiles)) != PB_OK) return rc;
+    }
+    apply_perm_kernel<<<grid_for(n, 256), 256, 0, ctx->stream>>>((const u64 *)ck.p, (const u32 *)cc.p, perm_a, n, W,
+                                                                (u64 *)ctx->ret_keys.p, (u16 *)ctx->ret_counts.p);
+    HIPCHK(hipGetLastError());
+    return tm.stop();
+}
+
 extern "C" {
 
 int pb_count(pb_ctx *ctx, unsigned k, uint64_t *occ_hist, uint64_t *max_occ, uint64_t *n_instances, uint64_t *n_distinct)
@@ -771,33 +811,8 @@ int pb_retain(pb_ctx *ctx, unsigned min_occ, uint64_t *n_keys)
     }
     HIPCHK(hipMemcpyAsync(&n, ctx->d_scalars.p, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    ctx->n_retained = n;
-    if ((rc = ensure(ctx, ctx->ret_keys, std::max<u64>(n, 1) * W * 8)) != PB_OK) return rc;
-    if ((rc = ensure(ctx, ctx->ret_counts, std::max<u64>(n, 1) * 2)) != PB_OK) return rc;
     if (n_keys) *n_keys = n;
-    if (n == 0) return PB_OK;
-    if (n >= (1ull << 32)) { ctx->err = "more than 2^32 retained k-mers on one GPU"; return PB_ERANGE; }
-    // LSD radix sort of a permutation, one key word at a time (least significant word first)
-    const u32 n_tiles = (u32)((n + RS_TILE - 1) / RS_TILE);
-    DevBuf &sk_a = ctx->scratch[4], &sk_b = ctx->scratch[5], &pv = ctx->scratch[0], &cn = ctx->scratch[1];
-    if ((rc = ensure(ctx, sk_a, n * 8)) != PB_OK) return rc;
-    if ((rc = ensure(ctx, sk_b, n * 8)) != PB_OK) return rc;
-    if ((rc = ensure(ctx, pv, n * 4 * 2)) != PB_OK) return rc;
-    if ((rc = ensure(ctx, cn, ((u64)256 * n_tiles + (u64)256 * n_tiles / RS_SCAN_CHUNK + 16) * 4)) != PB_OK) return rc;   // digit counts + scan block sums
-    u32 *perm_a = (u32 *)pv.p, *perm_b = perm_a + n;
-    StageTimer tm(ctx, "sort");
-    iota_kernel<<<grid_for(n, 256), 256, 0, ctx->stream>>>(perm_a, n);
-    const unsigned total_bits = 2 * ctx->k;
-    for (int w = 0; w < W; ++w) {
-        const unsigned bits = std::min<unsigned>(64u, total_bits - 64u * (unsigned)w);
-        gather_word_kernel<<<grid_for(n, 256), 256, 0, ctx->stream>>>((const u64 *)ck.p, perm_a, n, W, w, (u64 *)sk_a.p);
-        if ((rc = radix_sort_pairs(ctx, (u64 *)sk_a.p, perm_a, (u64 *)sk_b.p, perm_b, n, bits, (u32 *)cn.p, n_tiles)) != PB_OK) return rc;
-    }
-    apply_perm_kernel<<<grid_for(n, 256), 256, 0, ctx->stream>>>((const u64 *)ck.p, (const u32 *)cc.p, perm_a, n, W,
-                                                                (u64 *)ctx->ret_keys.p, (u16 *)ctx->ret_counts.p);
-    HIPCHK(hipGetLastError());
-    if ((rc = tm.stop()) != PB_OK) return rc;
-    return PB_OK;
+    return sort_retained(ctx, n);
 }
 
 int pb_fetch_retained(pb_ctx *ctx, uint64_t *keys, uint16_t *counts)
@@ -1107,3 +1122,4 @@ int pb_merge_end(pb_ctx *ctx, uint64_t *occ_hist, uint64_t *max_occ, uint64_t *n
 #include "graph_multik.inc"
 #include "chains.inc"
 #include "kmer_occ_layout.inc"
+#include "dist.inc"

@@ -81,7 +81,10 @@ struct Driver {
         if (!creator.joinable()) return;
         creator.join();
         if (create_rc != PB_OK) throw GpuError(create_rc, std::string("libpbgpu: ") + pb_last_error(nullptr));
+        if (dist()) chk(pb_dist_attach(ctx, opt.shared, opt.rank, opt.world, opt.rccl ? 1 : 0));
     }
+    bool dist() const { return opt.world > 1; }    // N ranks on this run: the table is merged over them before every graph stage
+    bool writer() const { return opt.rank == 0; }  // every rank computes the same graph; rank 0 writes the files
     ~Driver()
     {
         if (creator.joinable()) creator.join();
@@ -92,7 +95,7 @@ struct Driver {
     void log(const std::string &s) const { if (opt.verbose) std::cerr << s << std::endl; }
 
     // sortedKeyFromKmerFile + loadKmer + makeInitialBruijnGraph (assemble.cpp:343-358 / 474-478 / 613-617)
-    template <int W> void retain_and_build(unsigned kk, u64 min_occ)
+    template <int W> void retain_and_build(unsigned kk, u64 min_occ, bool shards = true)
     {
         u64 n = 0;
         log("loading kmers...");
@@ -103,6 +106,12 @@ struct Driver {
         {
             Tick t("retain+sort (device)");
             chk(pb_retain(ctx, (unsigned)min_occ, &n));
+        }
+        if (dist() && shards) {
+            // the table is spread over the ranks by owner stripe: every rank takes in the retained part of all shards (one
+            // table feeds loadKmer and makeInitialBruijnGraph, assemble.cpp:343-354)
+            Tick t("gather of the retained shards (ranks)");
+            chk(pb_dist_gather_retained(ctx, &n));
         }
         Graph<W> &g = graph<W>();
         g.set_k(kk);
@@ -175,6 +184,10 @@ struct Driver {
             Tick t("count k0 (device)");
             chk(pb_count(ctx, k[0], occ_hist.data(), &max_occ, &n_inst, &n_distinct));
         }
+        if (dist()) {
+            Tick t("owner exchange + merge of the occurrence tables (ranks)");
+            chk(pb_dist_merge_counts(ctx, occ_hist.data(), &max_occ, &n_distinct));
+        }
         const u64 llm = left_local_minimal_value(occ_hist, max_occ, 1);
         if (!opt.repeat) cutoff.push_back(opt.n_cutoff != 0 ? opt.n_cutoff : std::max<u64>(llm / 2, 2ull));
         else cutoff.push_back(opt.n_cutoff != 0 ? opt.n_cutoff : std::max<u64>(llm, 2ull));
@@ -184,6 +197,7 @@ struct Driver {
         {
             Tick t("read length histogram (device)");
             chk(pb_reads_length_hist(ctx, len_hist.data(), len_hist.size()));
+            if (dist()) chk(pb_dist_allreduce_u64(ctx, len_hist.data(), len_hist.size()));
         }
         avg_len = dist_average(len_hist, 0, 500000);
         avg_cov = avg_cov * avg_len / (avg_len - k[0] + 1.0);
@@ -192,7 +206,7 @@ struct Driver {
 
         std::ostringstream oss;
         oss << opt.out_prefix << '_' << k[0] << "merFrq.tsv";
-        {
+        if (writer()) {
             std::ofstream ofs(oss.str().c_str());                                  // counter.h:999-1007
             for (u64 i = 1; i <= max_occ; ++i) ofs << i << "\t" << occ_hist[i] << std::endl;
         }
@@ -333,7 +347,8 @@ struct Driver {
         u64 nd = 0;
         {
             Tick t("count missing k-mers (device)");
-            chk(pb_count_considering_contigs(ctx, kk, occ_hist.data(), &max_occ, &nd));
+            if (dist()) chk(pb_dist_count_considering_contigs(ctx, kk, occ_hist.data(), &max_occ, &nd));
+            else chk(pb_count_considering_contigs(ctx, kk, occ_hist.data(), &max_occ, &nd));
         }
         if (opt.verbose) std::cerr << "COVERAGE_CUTOFF = " << cutoff[position] << std::endl;
         retain_and_build<W>(kk, cutoff[position]);
@@ -372,7 +387,7 @@ struct Driver {
         if (atoi(opt.bubble.c_str()) > 0) {                     // assemble.cpp:520-526 (Q1: only -u >= 1 gets here)
             if (opt.verbose) std::cerr << "AVE_KMER_COV_REMOVING_BUBBLE=" << avg_cov << std::endl;
             g.crush_bubble_iterative(avg_cov, opt.verbose);
-            print_bubbles(opt.out_prefix + "_contigBubble.fa", g.bubbles, avg_len / (avg_len - kk + 1.0));
+            if (writer()) print_bubbles(opt.out_prefix + "_contigBubble.fa", g.bubbles, avg_len / (avg_len - kk + 1.0));
         }
         // saveGraph(k, allReadFP): diff == 0, so no edge k-mer is stored and no read survives
         chk(pb_reads_restore(ctx));
@@ -385,8 +400,9 @@ struct Driver {
         if (opt.verbose) std::cerr << "K = " << kk << ", loading kmers from contigs..." << std::endl;
         if (opt.verbose) std::cerr << "K = " << kk << ", saving additional kmers(not found in contigs) from reads..." << std::endl;
         u64 nd = 0;
+        // (no read is left on any rank, so this is the contig-derived table alone: the same on every rank, nothing to merge)
         chk(pb_count_considering_contigs(ctx, kk, occ_hist.data(), &max_occ, &nd));
-        retain_and_build<W>(kk, cutoff[num_k - 1]);
+        retain_and_build<W>(kk, cutoff[num_k - 1], false);
         Tick t("contig records (host)");
         g.save_contig_simple(contigs, avg_len / (avg_len - kk + 1.0));
         g.save_junction(junctions, avg_len / (avg_len - kk + 1.0));
@@ -408,6 +424,9 @@ template <typename F> void dispatch_w(unsigned k, F &&f)
 int run_assemble_gpu(const GpuAssembleOptions &opt)
 {
     if (opt.repeat) throw std::runtime_error("-repeat is outside the scope of the device path (DESIGN.md section 1)");
+    if (opt.world > 1 && opt.kmer_occ_only)
+        throw std::runtime_error("-kmer_occ_only with -gpus > 1: the slot layout of PREFIX_kmer_occ.bin is defined by the order in which ONE process first sees "
+                                 "every k-mer (counter.h:458-476 at -t 1); run it on one GPU");
     const auto t_start = std::chrono::steady_clock::now();
     Driver d(opt);
     auto print_timing = [&]() {
@@ -455,18 +474,27 @@ int run_assemble_gpu(const GpuAssembleOptions &opt)
             Tick t("device allocation for the read stream");
             u64 tb = 0, tr = 0;
             for (size_t i = base; i < hi_f; ++i) for (const ParsedPiece &pc : fpieces[i]) { tb += pc.bases.size(); tr += pc.off.size() - 1; }
+            if (opt.world > 1) { tb = tb / (u64)opt.world + (1u << 20); tr = tr / (u64)opt.world + 1024; }     // this rank's share
             d.chk(pb_reads_reserve(d.ctx, tb, tr));
         }
         for (size_t i = base; i < hi_f; ++i) {
             if (ferr[i]) std::rethrow_exception(ferr[i]);
             Tick t("upload + pack reads (H2D + device)");
+            // N ranks: rank r takes reads [r n / N, (r + 1) n / N) of every file (n = the file's reads).  The table that comes out
+            // of the merge does not depend on the partition (counts are sums), so any partition gives the reference's files.
+            u64 n_file = 0, seen = 0;
+            for (const ParsedPiece &pc : fpieces[i]) n_file += pc.off.size() - 1;
+            const u64 take_lo = opt.world > 1 ? n_file * (u64)opt.rank / (u64)opt.world : 0;
+            const u64 take_hi = opt.world > 1 ? n_file * (u64)(opt.rank + 1) / (u64)opt.world : n_file;
             for (ParsedPiece &pc : fpieces[i]) {
                 const std::vector<u64> &off = pc.off;
-                const u64 n = off.size() - 1;
-                u64 lo = 0;                          // batches of ~256 MB of bases
-                while (lo < n) {
+                const u64 n_piece = off.size() - 1;
+                const u64 p_lo = std::min(n_piece, take_lo > seen ? take_lo - seen : 0), p_hi = std::min(n_piece, take_hi > seen ? take_hi - seen : 0);
+                seen += n_piece;
+                u64 lo = p_lo;                       // batches of ~256 MB of bases
+                while (lo < p_hi) {
                     u64 hi = lo;
-                    while (hi < n && off[hi + 1] - off[lo] < (256ull << 20)) ++hi;
+                    while (hi < p_hi && off[hi + 1] - off[lo] < (256ull << 20)) ++hi;
                     if (hi == lo) ++hi;
                     d.chk(pb_reads_append(d.ctx, (const uint8_t *)pc.bases.data(), off.data() + lo, hi - lo, 1));
                     lo = hi;
@@ -509,7 +537,7 @@ int run_assemble_gpu(const GpuAssembleOptions &opt)
     const unsigned klast = d.k[d.num_k - 1];
     dispatch_w(klast, [&](auto w) { d.template output_and_after<decltype(w)::value>(klast); });
     const std::string out = opt.out_prefix + "_contig.fa";
-    {
+    if (d.writer()) {
         Tick t("write contigs");
         print_contigs(out, d.contigs, 1.0, d.avg_len, klast, "seq", false);
         print_contigs(out, d.junctions, 1.0, d.avg_len, klast, "junction", true);

@@ -22,6 +22,10 @@ struct GpuAssembleOptions {
     bool repeat = false;
     bool verbose = true;
     int device = 0;                      // not in the reference: which GPU
+    // not in the reference: N ranks (processes) on one run, reads range-partitioned over them
+    int rank = 0, world = 1;
+    void *shared = nullptr;              // pb_dist_shared_create's block, made before the ranks were forked
+    bool rccl = true;                    // record exchange over RCCL (one GPU per rank); false: through shared host memory
 };
 
 int run_assemble_gpu(const GpuAssembleOptions &opt);

@@ -8,6 +8,14 @@
 #include <cstring>
 #include "errors.hpp"
 #include <iostream>
+#include <csignal>
+#include <sys/mman.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
+extern "C" {
+#include "../../include/pbgpu.h"
+}
 
 static void usage()
 {
@@ -28,7 +36,12 @@ static void usage()
               << "    -m INT               : memory limit for making kmer distribution (GB, >=1, default 16; sizes PREFIX_kmer_occ.bin only)\n"
               << "    -tmp DIR             : directory for temporary files (accepted, unused: no temporary files)\n"
               << "    -kmer_occ_only       : only output k-mer occurrence table (out_kmer_occ.bin; default off) \n"
-              << "    -gpu INT             : device id (default 0)\n"
+              << "    -gpu INT             : device id (default 0; with -gpus N: rank r runs on device INT + r)\n"
+              << "    -gpus INT            : number of GPUs = processes (default 1): the reads are range-partitioned over them, the k-mer tables are\n"
+              << "                           merged by key owner over RCCL before every graph stage; same output files\n"
+              << "    -share_gpu           : with -gpus N: all ranks on device -gpu, records exchanged through shared host memory (tests)\n"
+              << "    -comm STR            : with -gpus N: rccl (default) or host (shared host memory instead of RCCL)\n"
+              << "    (-repeat is refused: the reference itself crashes in that mode, DESIGN.md section 1)\n"
               << "\n\nOutputs:\n    PREFIX_contig.fa\n    PREFIX_kmerFrq.tsv\n\nNote, PREFIX is specified by -o\n" << std::endl;
 }
 
@@ -133,6 +146,9 @@ int main(int argc, char **argv)
         return 1;
     }
     pbh::GpuAssembleOptions o;
+    int n_ranks = 1;
+    bool share_gpu = false;
+    std::string comm = "rccl";
     for (int i = 2; i < argc; ++i) {
         const std::string a = argv[i];
         auto val = [&]() -> std::string { if (i + 1 >= argc) { usage(); exit(1); } return argv[++i]; };
@@ -150,19 +166,62 @@ int main(int argc, char **argv)
         else if (a == "-m") o.memory_gb = atoi(val().c_str());
         else if (a == "-tmp") val();
         else if (a == "-gpu") o.device = atoi(val().c_str());
+        else if (a == "-gpus") n_ranks = atoi(val().c_str());
+        else if (a == "-share_gpu") share_gpu = true;
+        else if (a == "-comm") comm = val();
         else if (a == "-kmer_occ_only") o.kmer_occ_only = true;
         else if (a == "-repeat") o.repeat = true;
-        else if (a == "-f") { while (i + 1 < argc && argv[i + 1][0] != '-') o.files.push_back(argv[++i]); }
+        else if (a == "-f") { o.files.clear(); while (i + 1 < argc && argv[i + 1][0] != '-') o.files.push_back(argv[++i]); }   // (a repeated -f replaces the list, baseCommand.cpp:70)
         else { usage(); return 1; }              // unknown option / -h: usage, exit 1 (main.cpp:114-117)
     }
     if (o.files.empty()) { usage(); return 1; }
+    if (n_ranks < 1 || n_ranks > 64 || (comm != "rccl" && comm != "host")) { usage(); return 1; }
+    // N ranks: the processes are forked HERE, before anything touches the GPU; what they share (barrier, headers, outboxes) is
+    // set up first so that every child inherits it
+    struct Ranks { pid_t pid[64]; } *ranks = nullptr;
+    if (n_ranks > 1) {
+        void *shared = nullptr;
+        if (pb_dist_shared_create(n_ranks, &shared) != PB_OK) { std::cerr << "Error: cannot set up the shared memory of " << n_ranks << " ranks" << std::endl; return 2; }
+        ranks = (Ranks *)mmap(nullptr, sizeof(Ranks), PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+        if (ranks == MAP_FAILED) { std::cerr << "Error: mmap" << std::endl; return 2; }
+        memset(ranks, 0, sizeof(Ranks));
+        ranks->pid[0] = getpid();
+        o.world = n_ranks;
+        o.shared = shared;
+        o.rccl = comm == "rccl" && !share_gpu;
+        fflush(nullptr);
+        for (int r = 1; r < n_ranks; ++r) {
+            const pid_t c = fork();
+            if (c < 0) { std::cerr << "Error: fork" << std::endl; for (int q = 1; q < r; ++q) kill(ranks->pid[q], SIGKILL); return 2; }
+            if (c == 0) { o.rank = r; o.verbose = false; break; }
+            ranks->pid[r] = c;
+        }
+        if (!share_gpu) o.device += o.rank;
+    }
+    // a rank that fails takes the others with it (they would wait for it at the next collective forever)
+    auto fail_all = [&]() { if (ranks) for (int r = 0; r < n_ranks; ++r) if (r != o.rank && ranks->pid[r] > 0) kill(ranks->pid[r], SIGKILL); };
+    int rc = 0;
     try {
-        return process_information(pbh::run_assemble_gpu(o));
+        rc = pbh::run_assemble_gpu(o);
     } catch (const pbh::RefError &e) {           // the reference's exceptions: message, exit status = error id (main.cpp:118-127, common.h:97-100)
         std::cerr << "Error(" << e.id << "): " << e.what() << std::endl;
+        fail_all();
+        if (o.rank) _exit(e.id ? e.id : 2);
         return e.id;
     } catch (const std::exception &e) {
         std::cerr << "Error: " << e.what() << std::endl;
+        fail_all();
+        if (o.rank) _exit(2);
         return 2;
     }
+    if (o.rank) { fflush(nullptr); _exit(rc); }
+    if (ranks)
+        for (int r = 1; r < n_ranks; ++r) {
+            int st = 0;
+            if (waitpid(ranks->pid[r], &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) {
+                std::cerr << "Error: rank " << r << " did not finish" << std::endl;
+                if (rc == 0) rc = 2;
+            }
+        }
+    return process_information(rc);
 }

@@ -73,6 +73,35 @@ def exchange_records_split(dist, torch, keys, counts16, n_single, n_multi, W: in
     return rk, rcnt, recv
 
 
+def gather_retained(dist, torch, keys: np.ndarray, counts: np.ndarray, W: int):
+    """All-gather of the owners' retained (key,count) shards: keys uint64 [n, W] (word 0 least significant),
+    counts uint16 [n] of THIS rank's shard -> (keys, counts) of the union on every rank, ascending by the 2k-bit key value, i.e. the
+    set the reference's sortedKeyFromKmerFile / loadKmer see (counter.h:916-951,599-640).  The C++ CLI does the same through
+    pb_dist_gather_retained; this is the torch.distributed form (RCCL on GPUs, gloo in the CPU tests)."""
+    world = dist.get_world_size()
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    n = int(len(counts))
+    sizes = torch.zeros(world, dtype=torch.int64, device=dev)
+    mine = torch.tensor([n], dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(sizes, mine)
+    sz = [int(x) for x in sizes.tolist()]
+    cap = max(max(sz), 1)
+    buf = np.zeros((cap, W + 1), dtype=np.int64)              # key words + the count in one row
+    if n:
+        buf[:n, :W] = np.ascontiguousarray(keys).reshape(n, W).view(np.int64)
+        buf[:n, W] = counts.astype(np.int64)
+    send = torch.from_numpy(buf).to(dev)
+    recv = torch.empty((world * cap, W + 1), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(recv, send)
+    allr = recv.cpu().numpy()
+    parts = [allr[r * cap:r * cap + sz[r]] for r in range(world)]
+    cat = np.concatenate(parts) if parts else np.zeros((0, W + 1), dtype=np.int64)
+    gk = np.ascontiguousarray(cat[:, :W]).view(np.uint64)
+    gc = cat[:, W].astype(np.uint16)
+    order = np.lexsort(tuple(gk[:, w] for w in range(W)))      # last key = most significant word (binstr.h:460-466)
+    return gk[order], gc[order]
+
+
 def exchange_and_merge(g, dist, world: int, rank: int):
     """g: GpuCounter that has just counted this rank's reads.  After the call g's table is this rank's owner
     shard of the global table and g.occ_hist / g.max_occ / g.n_distinct describe the GLOBAL distribution."""

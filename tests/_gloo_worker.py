@@ -12,7 +12,7 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from platanus_b_amd import synth  # noqa: E402
-from platanus_b_amd.multigpu import exchange_records, exchange_records_split, owner_of  # noqa: E402
+from platanus_b_amd.multigpu import exchange_records, exchange_records_split, gather_retained, owner_of  # noqa: E402
 from oracle.pyoracle import OracleCounter  # noqa: E402
 
 
@@ -60,6 +60,10 @@ def main():
         hist[c] += 1
     th = torch.from_numpy(hist)
     dist.all_reduce(th)
+    # the retained part (count >= 2) of every owner's shard, gathered and sorted on every rank: what the graph stage is given
+    mk = np.array([kk for kk, c in merged.items() if c >= 2], dtype=np.uint64).reshape(-1, W)
+    mc = np.array([c for c in merged.values() if c >= 2], dtype=np.uint16)
+    gk, gc = gather_retained(dist, torch, mk, mc, W)
     gathered = [None] * world
     dist.all_gather_object(gathered, merged)
     if rank == 0:
@@ -67,7 +71,8 @@ def main():
         for m in gathered:
             assert not (set(m) & set(union))          # owners are disjoint
             union.update(m)
-        json.dump({"hist": th.tolist(), "n": len(union), "records": sorted([list(kk) + [c] for kk, c in union.items()])}, open(out, "w"))
+        json.dump({"hist": th.tolist(), "n": len(union), "records": sorted([list(kk) + [c] for kk, c in union.items()]),
+                   "retained2": [[int(w) for w in kk] + [int(c)] for kk, c in zip(gk, gc)]}, open(out, "w"))
     dist.destroy_process_group()
 
 

@@ -61,6 +61,36 @@ def test_cli_contigs_and_histogram_identical_to_reference(name, run, manifest, t
             assert filecmp.cmp(got, gold, shallow=False), fn
 
 
+@pytest.mark.parametrize("world,name,run", [(2, "c2", "multik_n2"), (4, "c2", "multik_n2"), (3, "c1", "multik"), (2, "k45", "multik_k45"), (2, "het", "u1")])
+def test_cli_n_ranks_write_the_reference_files(world, name, run, manifest, tmp_path):
+    """`assemble -gpus N`: N processes, reads range-partitioned over them, owner exchange + merge of the occurrence tables, gather
+    of the retained shards before every graph stage, read filter and missing-k-mer count sharded by reads.
+    Here the ranks share the one GPU of the box and exchange through shared host memory (-share_gpu; RCCL refuses two ranks on a
+    device); the files must be the real reference's, byte for byte: 1-, 2- and 3-word keys, N bases, -u 1."""
+    case = manifest[name]
+    info = case["runs"][run]
+    from platanus_b_amd import synth
+    synth.write_pair_files(str(tmp_path / "in"), case["genome"], case["cov"], case["seed"], err=case["err"], n_rate=case["n_rate"], het=case.get("het", 0.0))
+    args = [a for a in info["args"]]
+    p = subprocess.run([BIN, "assemble", *args, "-gpus", str(world), "-share_gpu", "-o", "out", "-f", "in_1.fq", "in_2.fq"], cwd=tmp_path, capture_output=True,
+                       text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    for fn, meta in info["files"].items():
+        assert (tmp_path / fn).exists(), fn
+        assert _md5(tmp_path / fn) == meta["md5"], fn
+        gold = os.path.join(GOLDEN, f"{name}.{run}.{fn}")
+        if os.path.exists(gold):
+            assert filecmp.cmp(tmp_path / fn, gold, shallow=False), fn
+
+
+def test_cli_n_ranks_refuses_kmer_occ_only(tmp_path):
+    from platanus_b_amd import synth
+    synth.write_pair_files(str(tmp_path / "in"), 5000, 20, 3)
+    p = subprocess.run([BIN, "assemble", "-kmer_occ_only", "-gpus", "2", "-share_gpu", "-o", "out", "-f", "in_1.fq", "in_2.fq"], cwd=tmp_path, capture_output=True,
+                       text=True, timeout=300)
+    assert p.returncode != 0 and "one GPU" in p.stderr
+
+
 def test_cli_kmer_occ_only_byte_identical(manifest, tmp_path):
     """-kmer_occ_only (BASELINE configs[1]'s mode): TSV and PREFIX_kmer_occ.bin byte-identical to the reference's files
     (k = 32, -t 1 layout; md5 for the 1 MB file of the 50 kbp case)."""
@@ -136,6 +166,15 @@ def test_cli_config3_full_multik_5mbp_md5(manifest, tmp_path):
         assert os.path.getsize(tmp_path / fn) == meta["bytes"], fn
         assert _md5(tmp_path / fn) == meta["md5"], fn
     print(f"config 3 incl. FASTQ generation: {time.time() - t0:.1f} s")
+    # BASELINE configs[1] on the same files: `-kmer_occ_only` at the -t 1 schedule.  PREFIX_kmer_occ.bin (5,107,483 records of the
+    # 60.8 M distinct 32-mers, slot layout of the reference's three sequential insertions) is pinned by the md5 of the real
+    # reference's file (tests/golden/manifest.json cfg3.runs.occ_t1: 234 s of reference run).
+    occ = manifest["cfg3"]["runs"]["occ_t1"]
+    p = subprocess.run([BIN, "assemble", *occ["args"], "-o", "out", "-f", "in_1.fq", "in_2.fq"], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    for fn, meta in occ["files"].items():
+        assert os.path.getsize(tmp_path / fn) == meta["bytes"], fn
+        assert _md5(tmp_path / fn) == meta["md5"], fn
 
 
 def test_cli_piecewise_parser_equals_sequential_line_rules(manifest, tmp_path):

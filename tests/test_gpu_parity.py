@@ -257,6 +257,47 @@ def test_config2_full_size_through_the_cabi(gpu, manifest, tmp_path, monkeypatch
     assert np.array_equal(keys, kd) and np.array_equal(counts, cd)
 
 
+@pytest.mark.parametrize("name,G,cov,seed", [("configs[3]", 5_000_000, 1000.0, 1), ("configs[4]", 100_000_000, 100.0, 5)])
+def test_eight_gpu_configs_at_their_per_gpu_shard_shape(name, G, cov, seed, gpu):
+    """BASELINE configs[3] (5 Mbp x 1000x) and configs[4] (100 Mbp x 100x) as ONE of their 8 GPUs sees them before the merge: the
+    first eighth of the read pairs (496 M / 992 M windows; for the 100 Mbp genome that is 12.5x coverage, where most k-mers of the
+    shard are seen a handful of times).  Full-size property checks: the super-k-mer pass takes the input, sum(hist) = distinct,
+    sum(i * hist) = windows, the reverse complements of all reads give the same retained table, and the direct global-table pass
+    agrees with the super-k-mer pass on histogram and retained (key,count) set."""
+    from platanus_b_amd import synth
+    genome = synth.make_genome(G, seed)
+    n_pairs = int(G * cov) // 300 // 8
+    g, grc = gpu(0), gpu(0)
+    for lo in range(0, n_pairs, 250_000):
+        r1, r2 = synth.make_reads(G, cov, seed, genome=genome, pair_lo=lo, pair_hi=min(lo + 250_000, n_pairs))
+        g.reads_append_matrix(r1)
+        g.reads_append_matrix(r2)
+        grc.reads_append_matrix(np.ascontiguousarray(3 - r2[:, ::-1]))
+        grc.reads_append_matrix(np.ascontiguousarray(3 - r1[:, ::-1]))
+    h = g.make_kmer_read_distribution(32).copy()
+    assert g.kernel_ms("part1") > 0, "the super-k-mer pass must take a shard of this size"
+    print(f"{name} shard: {g.n_instances} windows, {g.n_distinct} distinct, 2^{int(g.kernel_ms('sk_bucket_bits'))} buckets, "
+          f"{int(g.kernel_ms('sk_flagged_buckets'))} flagged, {int(g.kernel_ms('sk_spilled_records'))} spilled records, kernels {g.kernel_ms('count'):.2f} ms")
+    assert g.n_instances == 2 * n_pairs * 119
+    assert int(h.sum()) == g.n_distinct
+    assert int((np.arange(65535, dtype=np.uint64) * h).sum()) == g.n_instances
+    n = g.retain(2)
+    keys, counts = g.fetch_retained()
+    assert n == len(counts) and (keys[1:, 0] > keys[:-1, 0]).all()
+    assert np.array_equal(h, grc.make_kmer_read_distribution(32))
+    grc.retain(2)
+    krc, crc = grc.fetch_retained()
+    assert np.array_equal(keys, krc) and np.array_equal(counts, crc)
+    del grc, krc, crc
+    g.set_option("count_path", COUNT_PATH["direct"])
+    hd = g.make_kmer_read_distribution(32)
+    assert g.kernel_ms("part1") == 0
+    assert np.array_equal(h, hd)
+    g.retain(2)
+    kd, cd = g.fetch_retained()
+    assert np.array_equal(keys, kd) and np.array_equal(counts, cd)
+
+
 @pytest.mark.parametrize("k", [32, 45])
 def test_export_buckets_and_merge_roundtrip(k, gpu, oracle_built):
     """X1 on one GPU: bucket the table into 8 owner parts, check every record sits in its owner's bucket, merge the

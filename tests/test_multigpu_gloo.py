@@ -33,6 +33,9 @@ def test_owner_exchange_world2_matches_single_process(k, port, mode, tmp_path, o
     assert res["hist"] == [int(x) for x in hist]
     want = sorted([[int(w) for w in kk] + [int(c)] for kk, c in zip(keys, counts)])
     assert res["records"] == want
+    # gather of the retained shards (cutoff 2): the sorted set the graph stage gets, in the oracle's order
+    k2, c2 = oc.retain(2)
+    assert res["retained2"] == [[int(w) for w in kk] + [int(c)] for kk, c in zip(k2, c2)]
 
 
 def test_owner_function_is_the_reference_stripe_range():
