@@ -72,6 +72,18 @@ def load_library() -> C.CDLL:
     lib.pb_merge_records.argtypes = [vp, C.c_uint, vp, vp, C.c_uint64, vp, u64p, u64p]
     lib.pb_kmer_occ_layout.argtypes = [vp, C.c_uint64, C.c_uint, u64p, u64p]
     lib.pb_kmer_occ_fetch.argtypes = [vp, vp, vp, vp]
+    lib.pb_graph_adjacency.argtypes = [vp, vp, vp]
+    lib.pb_graph_chains.argtypes = [vp, u64p, u64p]
+    lib.pb_graph_fetch_chains.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.pb_graph_nodes.argtypes = [vp, u64p]
+    lib.pb_graph_fetch_nodes.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    lib.pb_graph_fetch_chain_records.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.pb_reads_filter.argtypes = [vp, C.c_uint, vp, C.c_uint64, u64p]
+    lib.pb_reads_restore.argtypes = [vp]
+    lib.pb_contig_table_build.argtypes = [vp, C.c_uint, vp, vp, vp, C.c_uint64, u64p]
+    lib.pb_count_considering_contigs.argtypes = [vp, C.c_uint, vp, u64p, u64p]
+    lib.pb_occ_table_load.argtypes = [vp, C.c_uint, vp, vp, C.c_uint64]
+    lib.pb_occ_lookup.argtypes = [vp, vp, vp, C.c_uint64, vp]
     _lib = lib
     return lib
 
@@ -231,6 +243,85 @@ class GpuCounter:
             f.write(np.array([self.k, ts.value - 1], dtype="<u8").tobytes())
             f.write(rec.tobytes())
         return ts.value, n
+
+    # ---- graph stage (graph.h:289-579, device part) on the retained set of the last retain() ----
+    def graph_adjacency(self):
+        """adj uint8 [n], nbr uint32 [n, 2] (include/pbgpu.h pb_graph_adjacency)."""
+        n = self.n_retained
+        adj = np.zeros(max(n, 1), dtype=np.uint8)
+        nbr = np.zeros((max(n, 1), 2), dtype=np.uint32)
+        self._chk(self.lib.pb_graph_adjacency(self.h, adj.ctypes.data, nbr.ctypes.data))
+        return adj[:n], nbr[:n]
+
+    def graph_chains(self):
+        """dict of the per-k-mer and per-chain arrays of pb_graph_chains / pb_graph_fetch_chains."""
+        nc, words = C.c_uint64(), C.c_uint64()
+        self._chk(self.lib.pb_graph_chains(self.h, C.byref(nc), C.byref(words)))
+        n, c, w = self.n_retained, nc.value, words.value
+        r = dict(chain_of=np.zeros(max(n, 1), dtype=np.uint32), orient=np.zeros(max(n, 1), dtype=np.uint8), len=np.zeros(max(c, 1), dtype=np.uint32),
+                 sum=np.zeros(max(c, 1), dtype=np.uint64), end_a=np.zeros(max(c, 1), dtype=np.uint32), end_b=np.zeros(max(c, 1), dtype=np.uint32),
+                 seq_woff=np.zeros(max(c, 1), dtype=np.uint64), seq=np.zeros(max(w, 1), dtype=np.uint64))
+        self._chk(self.lib.pb_graph_fetch_chains(self.h, r["chain_of"].ctypes.data, r["orient"].ctypes.data, r["len"].ctypes.data, r["sum"].ctypes.data,
+                                                 r["end_a"].ctypes.data, r["end_b"].ctypes.data, r["seq_woff"].ctypes.data, r["seq"].ctypes.data))
+        for key in ("chain_of", "orient"):
+            r[key] = r[key][:n]
+        for key in ("len", "sum", "end_a", "end_b", "seq_woff"):
+            r[key] = r[key][:c]
+        r["n_chains"] = c
+        return r
+
+    def graph_nodes(self):
+        """Compact node export (pb_graph_nodes / pb_graph_fetch_nodes / pb_graph_fetch_chain_records); call after graph_chains()."""
+        W = words_for_k(self.k)
+        nn = C.c_uint64()
+        self._chk(self.lib.pb_graph_nodes(self.h, C.byref(nn)))
+        m = nn.value
+        r = dict(idx=np.zeros(max(m, 1), dtype=np.uint32), meta=np.zeros(max(m, 1), dtype=np.uint32), chain=np.zeros(max(m, 1), dtype=np.uint32),
+                 nbr=np.zeros((max(m, 1), 2), dtype=np.uint32), nb8=np.zeros((max(m, 1), 8), dtype=np.uint32), keys=np.zeros((max(m, 1), W), dtype=np.uint64))
+        self._chk(self.lib.pb_graph_fetch_nodes(self.h, r["idx"].ctypes.data, r["meta"].ctypes.data, r["chain"].ctypes.data, r["nbr"].ctypes.data,
+                                                r["nb8"].ctypes.data, r["keys"].ctypes.data))
+        return {key: v[:m] for key, v in r.items()}
+
+    # ---- multi-k rounds (assemble.cpp:392-498) ----
+    def reads_filter(self, k: int, edge_keys: np.ndarray) -> int:
+        """pickupReadMatchedEdgeKmer (counter.h:869-910): edge_keys uint64 [n, W] canonical; returns the number of reads kept."""
+        ek = np.ascontiguousarray(edge_keys, dtype=np.uint64)
+        kept = C.c_uint64()
+        self._chk(self.lib.pb_reads_filter(self.h, k, ek.ctypes.data, ek.shape[0] if ek.size else 0, C.byref(kept)))
+        return kept.value
+
+    def reads_restore(self):
+        self._chk(self.lib.pb_reads_restore(self.h))
+
+    def contig_table_build(self, k: int, bases: np.ndarray, offsets: np.ndarray, values: np.ndarray) -> int:
+        """saveContig<NEXT> (graph.h:1655-1771): contig strings (codes 0..3) with one value each -> the resident next-k table."""
+        b = np.ascontiguousarray(bases, dtype=np.uint8)
+        o = np.ascontiguousarray(offsets, dtype=np.uint64)
+        v = np.ascontiguousarray(values, dtype=np.uint16)
+        nw = C.c_uint64()
+        self._chk(self.lib.pb_contig_table_build(self.h, k, b.ctypes.data, o.ctypes.data, v.ctypes.data, len(v), C.byref(nw)))
+        return nw.value
+
+    def count_considering_contigs(self, k: int):
+        """makeKmerReadDistributionConsideringPreviousGraph (counter.h:662-750); afterwards retain() / fetch_all() work on the result."""
+        hist = np.zeros(PB_OCC_BINS, dtype=np.uint64)
+        mx, nd = C.c_uint64(), C.c_uint64()
+        self._chk(self.lib.pb_count_considering_contigs(self.h, k, hist.ctypes.data, C.byref(mx), C.byref(nd)))
+        self.k, self.occ_hist, self.max_occ, self.n_distinct = k, hist, mx.value, nd.value
+        return hist
+
+    # ---- kmer_divide's look-ups (kmer_divide.cpp:150-197) ----
+    def occ_table_load(self, k: int, keys: np.ndarray, counts: np.ndarray):
+        kk = np.ascontiguousarray(keys, dtype=np.uint64)
+        cc = np.ascontiguousarray(counts, dtype=np.uint16)
+        self._chk(self.lib.pb_occ_table_load(self.h, k, kk.ctypes.data, cc.ctypes.data, len(cc)))
+
+    def occ_lookup(self, bases: np.ndarray, offsets: np.ndarray) -> np.ndarray:
+        b = np.ascontiguousarray(bases, dtype=np.uint8)
+        o = np.ascontiguousarray(offsets, dtype=np.uint64)
+        out = np.zeros(max(int(o[-1] - o[0]), 1), dtype=np.uint16)
+        self._chk(self.lib.pb_occ_lookup(self.h, b.ctypes.data, o.ctypes.data, len(o) - 1, out.ctypes.data))
+        return out[:int(o[-1] - o[0])]
 
     def kernel_ms(self, stage: str) -> float:
         ms = C.c_float()

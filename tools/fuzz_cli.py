@@ -1,5 +1,7 @@
-"""Development aid: differential test of the whole `assemble` CLI (GPU build) against the oracle's CLI on random small inputs
-with repeats, inverted repeats and tandem repeats (junctions, hairpins, cycles in the graph) and random options.
+"""Development aid: differential test of the whole `assemble` CLI (GPU build) against the REAL reference binary (oracle/_ref/platanus_b,
+compiled from /root/reference by oracle/Makefile; it travels to the GPU box) -- or, where that binary is absent, against the oracle's
+CLI, which shares the node-level host headers with the product -- on random small inputs with repeats, inverted repeats and tandem
+repeats (junctions, hairpins, cycles in the graph) and random options; a third of the cases run the GPU side as 2 or 3 ranks.
 usage: python tools/fuzz_cli.py [n_cases] [seed] [min_genome] [max_genome]     (>= ~110 kbp at 40x reaches the super-k-mer pass)"""
 import filecmp
 import os
@@ -13,6 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 GPU = os.path.join(ROOT, "platanus_b_amd", "bin", "platanus_b")
 ORC = os.path.join(ROOT, "oracle", "pb_oracle")
+REF = os.path.join(ROOT, "oracle", "_ref", "platanus_b")
 
 
 def main():
@@ -22,6 +25,8 @@ def main():
     g_hi = int(sys.argv[4]) if len(sys.argv) > 4 else 40_000
     asc = np.frombuffer(b"ACGTN", dtype=np.uint8)
     bad = 0
+    checker = REF if os.path.exists(REF) else ORC
+    print(f"checker: {'reference' if checker == REF else 'oracle'} ({checker})", flush=True)
     for case in range(n_cases):
         G = int(rng.integers(g_lo, g_hi))
         g = rng.integers(0, 4, G).astype(np.uint8)
@@ -68,7 +73,9 @@ def main():
             if rng.random() < 0.2:
                 args += ["-e", str(rng.choice(["20", "45"]))]
             outs = {}
-            for name, binary, extra in (("orc", ORC, []), ("gpu", GPU, [])):
+            ranks = int(rng.choice([1, 1, 2, 3]))
+            gpu_extra = ["-gpus", str(ranks), "-share_gpu"] if ranks > 1 else []
+            for name, binary, extra in (("orc", checker, ["-t", "1"]), ("gpu", GPU, gpu_extra)):
                 d = os.path.join(td, name)
                 os.mkdir(d)
                 p = subprocess.run([binary, "assemble", *args, *extra, "-o", "out", "-f", "../in_1.fq", "../in_2.fq"], cwd=d, capture_output=True, text=True,
@@ -88,7 +95,7 @@ def main():
                 print(f"MISMATCH case {case}: G={G} cov={cov} err={err} RL={RL} args={' '.join(args)} rc={outs['orc'][0]}/{outs['gpu'][0]}", flush=True)
             else:
                 nct = sum(1 for l in open(os.path.join(outs["gpu"][1], "out_contig.fa")) if l.startswith(">")) if outs["gpu"][0] == 0 else -1
-                print(f"case {case}: ok (G={G} cov={cov} err={err} args={' '.join(args)} rc={outs['gpu'][0]} records={nct})", flush=True)
+                print(f"case {case}: ok (G={G} cov={cov} err={err} args={' '.join(args)} ranks={ranks} rc={outs['gpu'][0]} records={nct})", flush=True)
     print(f"{n_cases} cases, {bad} mismatches")
     sys.exit(1 if bad else 0)
 

@@ -1,5 +1,6 @@
-"""Development aid: differential test of the `kmer_divide` and `merge` commands (GPU build vs the oracle's CLI) on the contigs and
-the k-mer occurrence table of random heterozygous read sets, with random options.
+"""Development aid: differential test of the `kmer_divide` and `merge` commands (GPU build vs the REAL reference binary
+oracle/_ref/platanus_b where it is present, else the oracle's CLI) on the contigs and the k-mer occurrence table of random
+heterozygous read sets, with random options.
 usage: python tools/fuzz_cli2.py [n_cases] [seed]"""
 import filecmp
 import os
@@ -13,6 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 GPU = os.path.join(ROOT, "platanus_b_amd", "bin", "platanus_b")
 ORC = os.path.join(ROOT, "oracle", "pb_oracle")
+REF = os.path.join(ROOT, "oracle", "_ref", "platanus_b")
 
 
 def run(binary, args, cwd):
@@ -24,6 +26,8 @@ def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 10
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     bad = 0
+    checker = REF if os.path.exists(REF) else ORC
+    print(f"checker: {'reference' if checker == REF else 'oracle'} ({checker})", flush=True)
     for case in range(n_cases):
         G = int(rng.integers(8_000, 60_000))
         with tempfile.TemporaryDirectory() as td:
@@ -36,7 +40,7 @@ def main():
             ok = True
             for cmd, args, inputs in (("kmer_divide", kd, ["-k", "../occ_kmer_occ.bin", "-f", "../asm_contig.fa"]), ("merge", mg, ["-f", "../asm_contig.fa"])):
                 dirs = {}
-                for name, binary in (("orc", ORC), ("gpu", GPU)):
+                for name, binary in (("orc", checker), ("gpu", GPU)):
                     d = os.path.join(td, f"{cmd}_{name}")
                     os.mkdir(d)
                     dirs[name] = (run(binary, [cmd, *args, "-o", "out", *inputs], d).returncode, d)
