@@ -373,11 +373,19 @@ static int upload_bases(pb_ctx *ctx, unsigned char *dst, const uint8_t *src, u64
         HIPCHK(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, ctx->stream));
         return PB_OK;
     }
-    if (!ctx->bounce[0]) {
+    if (!ctx->copy_pool) {                     // (keyed on the last thing set up: a failure half-way leaves nothing that looks ready)
+        void *bb[2] = {nullptr, nullptr};
+        hipEvent_t be[2] = {nullptr, nullptr};
         for (int b = 0; b < 2; ++b) {
-            HIPCHK(hipHostMalloc(&ctx->bounce[b], CH, hipHostMallocDefault));
-            HIPCHK(hipEventCreateWithFlags(&ctx->bounce_ev[b], hipEventDisableTiming));
+            hipError_t e = hipHostMalloc(&bb[b], CH, hipHostMallocDefault);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&be[b], hipEventDisableTiming);
+            if (e != hipSuccess) {
+                for (int q = 0; q < 2; ++q) { if (bb[q]) (void)hipHostFree(bb[q]); if (be[q]) (void)hipEventDestroy(be[q]); }
+                ctx->err = std::string("pinned staging buffers: ") + hipGetErrorString(e);
+                return PB_ENOMEM;
+            }
         }
+        for (int b = 0; b < 2; ++b) { ctx->bounce[b] = bb[b]; ctx->bounce_ev[b] = be[b]; }
         ctx->copy_pool = new CopyPool();
         ctx->copy_pool->start(std::min(8u, std::max(1u, std::thread::hardware_concurrency())));
     }
@@ -417,9 +425,11 @@ int pb_reads_append(pb_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, 
     auto now = []() { return std::chrono::steady_clock::now(); };
     auto t0 = now();
     auto lap = [&](const char *what) { if (trace) { auto t1 = now(); fprintf(stderr, "  append %-10s %.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count()); t0 = t1; } };
+    // every length is checked before the context changes: a refused batch leaves no trace (lengthDistribution stays what it was)
+    for (u64 r = 0; r < n_reads; ++r)
+        if (offsets[r + 1] - offsets[r] >= 500000) { ctx->err = "read of 500000 bases or more (common.cpp:28)"; return PB_ERANGE; }
     for (u64 r = 0; r < n_reads; ++r) {
         const u64 len = offsets[r + 1] - offsets[r];
-        if (len >= 500000) { ctx->err = "read of 500000 bases or more (common.cpp:28)"; return PB_ERANGE; }
         if (len >= ctx->len_hist.size()) ctx->len_hist.resize(len + 1, 0);
         ++ctx->len_hist[len];
     }

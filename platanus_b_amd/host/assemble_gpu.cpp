@@ -203,6 +203,11 @@ struct Driver {
         avg_cov = avg_cov * avg_len / (avg_len - k[0] + 1.0);
         if (opt.verbose) std::cerr << "AVE_READ_LEN=" << avg_len << std::endl;
         num_k = extend_kmer(min_log_p_join, avg_cov, avg_len, opt.min_cov, opt.max_k_ratio, k, cutoff, opt.step, opt.verbose);
+        // the device keys have at most five words (KmerN<Binstr159>, assemble.cpp:174-185); the reference's sixth type (binstr_t,
+        // k > 160) needs reads of 321 bases or more at the default -K 0.5: refused here, before any graph work, not in the middle
+        if (!k.empty() && k.back() > 160)
+            throw std::runtime_error("the k schedule reaches k = " + std::to_string(k.back()) + " (-K times the average read length); this build supports k <= 160: "
+                                     "lower -K or give a smaller maximum k");
 
         std::ostringstream oss;
         oss << opt.out_prefix << '_' << k[0] << "merFrq.tsv";
@@ -273,8 +278,8 @@ struct Driver {
         base = std::log(tmp) / std::log(2);
         tmp = std::pow(2, base);
         while (tmp > memory) tmp >>= 1;
-        u64 size = std::log(n / 0.9) / std::log(2);
-        size = std::pow(2, size + 1);
+        u64 size = n ? (u64)(std::log(n / 0.9) / std::log(2)) : 0;      // (no record: log(0) is not taken; the table has the -m size)
+        size = n ? (u64)std::pow(2, size + 1) : 0;
         const u64 slots = std::max(size, tmp);
         const u64 nmask = slots - 1;
         unsigned index_len = 64;
