@@ -645,10 +645,11 @@ static int count_superk(pb_ctx *ctx, unsigned k, bool *done)
         {
             // one host synchronisation for the three kernels (the flags are needed before anything else is decided)
             LazyTimer t1(ctx, "part1", 0);
-            const u64 n_tiles = (ctx->stream_len + SK_OWN - 1) / SK_OWN;
+            const u64 n_tiles = (ctx->stream_len + SK1_OWN - 1) / SK1_OWN;
+            const size_t dig_bytes = (size_t)3 * 4 * (1u << p.l1);
             const u64 nw64 = (ctx->stream_len + 63) / 64 + PB_STREAM_PAD_WORDS64;
-            if (k == 32) sk_part1_kernel<32><<<grid_for(n_tiles, 1, 256 * 8), SK_THREADS, 0, ctx->stream>>>((const u64 *)ctx->packed.p, cur_mask(ctx), ctx->stream_len, nw64, p);
-            else sk_part1_kernel<0><<<grid_for(n_tiles, 1, 256 * 8), SK_THREADS, 0, ctx->stream>>>((const u64 *)ctx->packed.p, cur_mask(ctx), ctx->stream_len, nw64, p);
+            if (k == 32) sk_part1_kernel<32><<<grid_for(n_tiles, 1, 256 * 16), SK1_THREADS, dig_bytes, ctx->stream>>>((const u64 *)ctx->packed.p, cur_mask(ctx), ctx->stream_len, nw64, p);
+            else sk_part1_kernel<0><<<grid_for(n_tiles, 1, 256 * 16), SK1_THREADS, dig_bytes, ctx->stream>>>((const u64 *)ctx->packed.p, cur_mask(ctx), ctx->stream_len, nw64, p);
             t1.stop();
             LazyTimer t2(ctx, "part2", 1);
             // a few blocks per sub-stream, each striding over its tiles (most of cap1 is head-room: one block per tile would be mostly empty blocks)
@@ -671,6 +672,21 @@ static int count_superk(pb_ctx *ctx, unsigned k, bool *done)
             fprintf(stderr, "[pbgpu] super-k-mer pass: k %u, 2^%u buckets (l1 %u), cap1 %llu cap2 %u: windows %llu, records %llu, distinct %llu, flagged buckets %llu, "
                             "spilled records %llu, overflow %llu\n", k, B, p.l1, (unsigned long long)p.cap1, p.cap2, (unsigned long long)sc[0], (unsigned long long)sc[6],
                     (unsigned long long)sc[4], (unsigned long long)sc[7], (unsigned long long)sc[8], (unsigned long long)sc[1]);
+#ifdef SK_DBG
+        if (ctx->opt_verbose) {
+            unsigned long long v[5] = {0, 0, 0, 0, 0};
+            (void)hipMemcpyFromSymbol(&v[0], HIP_SYMBOL(sk_dbg_probe_iters), 8); (void)hipMemcpyFromSymbol(&v[1], HIP_SYMBOL(sk_dbg_flushes), 8);
+            (void)hipMemcpyFromSymbol(&v[2], HIP_SYMBOL(sk_dbg_parked), 8); (void)hipMemcpyFromSymbol(&v[3], HIP_SYMBOL(sk_dbg_steps), 8);
+            (void)hipMemcpyFromSymbol(&v[4], HIP_SYMBOL(sk_dbg_inserts), 8);
+            unsigned long long cyc[12];
+            (void)hipMemcpyFromSymbol(cyc, HIP_SYMBOL(sk_dbg_cyc), 96);
+            unsigned long long tot = 0;
+            for (int i = 0; i < 12; ++i) tot += cyc[i];
+            static const char *nm[12] = {"bucket prologue", "wait for the records", "phase A", "barrier A", "scan + piece map", "keys + CAS + add", "parking", "clear + last flush", "barrier B", "emit", "", ""};
+            for (int i = 0; i < 10; ++i) fprintf(stderr, "[pbgpu]   wave cycles %-22s %5.1f %%\n", nm[i], 100.0 * (double)cyc[i] / (double)tot);
+            fprintf(stderr, "[pbgpu]   dbg (cumulative): slow-probe iterations %llu, queue flushes %llu, parked keys %llu, piece steps %llu, window inserts %llu\n", v[0], v[1], v[2], v[3], v[4]);
+        }
+#endif
         if (ctx->opt_verbose && sc[7]) {
             std::vector<u32> fl(nb2), cu(nb2);
             (void)hipMemcpy(fl.data(), p.flag2, nb2 * 4, hipMemcpyDeviceToHost);
