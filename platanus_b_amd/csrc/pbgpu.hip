@@ -109,6 +109,7 @@ struct pb_ctx {
     DevBuf dist_keys, dist_counts;      // u64[n*W], u32[n]
     int count_path = 0;                 // 1 = direct (v1), 2 = partitioned (v2)
     DevBuf part_bucket1, part_bucket2, part_meta, part_spill;
+    DevBuf part_pos1, part_pos2, sk_first;   // position-carrying pass (pb_kmer_occ_layout): record positions, first occurrence per distinct k-mer
     void *bounce[2] = {nullptr, nullptr};   // pinned staging buffers of upload_bases
     hipEvent_t bounce_ev[2];
     bool bounce_used[2] = {false, false};
@@ -290,7 +291,7 @@ void pb_destroy(pb_ctx *ctx)
     (void)pb_dist_detach(ctx);
     release(ctx->packed); release(ctx->nmask); release(ctx->table); release(ctx->d_hist); release(ctx->d_scalars);
     release(ctx->ret_keys); release(ctx->ret_counts); release(ctx->exp_keys); release(ctx->exp_counts); release(ctx->merge_table);
-    release(ctx->dist_keys); release(ctx->dist_counts); release(ctx->part_bucket1); release(ctx->part_bucket2); release(ctx->part_meta); release(ctx->part_spill);
+    release(ctx->dist_keys); release(ctx->dist_counts); release(ctx->part_pos1); release(ctx->part_pos2); release(ctx->sk_first); release(ctx->part_bucket1); release(ctx->part_bucket2); release(ctx->part_meta); release(ctx->part_spill);
     release(ctx->index_table); release(ctx->node_mark); release(ctx->node_idx); release(ctx->node_rec); release(ctx->nmask_cur); release(ctx->alive); release(ctx->d_read_start);
     release(ctx->contig_packed); release(ctx->contig_mask); release(ctx->ctable);
     release(ctx->chain_work); release(ctx->chain_rec); release(ctx->chain_seq);
@@ -583,7 +584,7 @@ static int count_direct(pb_ctx *ctx, unsigned k)
 }
 
 // v2: super-k-mer records, two-level partition by minimizer bucket, LDS-resident counting (k <= 32)
-static int count_superk(pb_ctx *ctx, unsigned k, bool *done)
+static int count_superk(pb_ctx *ctx, unsigned k, bool *done, bool want_pos = false)
 {
     int rc;
     *done = false;
@@ -619,6 +620,13 @@ static int count_superk(pb_ctx *ctx, unsigned k, bool *done)
         if ((rc = ensure(ctx, ctx->part_meta, (nb1 + 2 * nb2) * 4)) != PB_OK) return rc;
         p.spill_cap = std::max<u64>((u64)(est_rec / 16), 1ull << 16);
         if ((rc = ensure(ctx, ctx->part_spill, p.spill_cap * SkStore16::BYTES)) != PB_OK) return rc;
+        p.pos1 = p.pos2 = nullptr;
+        if (want_pos) {
+            if ((rc = ensure(ctx, ctx->part_pos1, nb1 * p.cap1 * 4)) != PB_OK) return rc;
+            if ((rc = ensure(ctx, ctx->part_pos2, (nb2 * (u64)p.cap2 + 1024) * 4)) != PB_OK) return rc;
+            p.pos1 = (u32 *)ctx->part_pos1.p;
+            p.pos2 = (u32 *)ctx->part_pos2.p;
+        }
         p.spill = ctx->part_spill.p;
         p.bucket1 = ctx->part_bucket1.p;
         p.bucket2 = ctx->part_bucket2.p;
@@ -629,6 +637,7 @@ static int count_superk(pb_ctx *ctx, unsigned k, bool *done)
         const u64 out_cap = std::min<u64>(std::max<u64>(ctx->stream_len, 1), nb2 * (u64)SK_SLOT_LIMIT);
         if ((rc = ensure(ctx, ctx->dist_keys, (out_cap + fcap) * 8)) != PB_OK) return rc;
         if ((rc = ensure(ctx, ctx->dist_counts, (out_cap + fcap) * 4)) != PB_OK) return rc;
+        if (want_pos && (rc = ensure(ctx, ctx->sk_first, (out_cap + fcap) * 4)) != PB_OK) return rc;
         if ((rc = ensure(ctx, ctx->table, fcap * 16)) != PB_OK) return rc;
         ctx->table_cap = fcap;
         p.fallback = TableView<1>{(u64 *)ctx->table.p, fcap - 1};
@@ -648,18 +657,23 @@ static int count_superk(pb_ctx *ctx, unsigned k, bool *done)
             const u64 n_tiles = (ctx->stream_len + SK1_OWN - 1) / SK1_OWN;
             const size_t dig_bytes = (size_t)3 * 4 * (1u << p.l1);
             const u64 nw64 = (ctx->stream_len + 63) / 64 + PB_STREAM_PAD_WORDS64;
-            if (k == 32) sk_part1_kernel<32><<<grid_for(n_tiles, 1, 256 * 16), SK1_THREADS, dig_bytes, ctx->stream>>>((const u64 *)ctx->packed.p, cur_mask(ctx), ctx->stream_len, nw64, p);
-            else sk_part1_kernel<0><<<grid_for(n_tiles, 1, 256 * 16), SK1_THREADS, dig_bytes, ctx->stream>>>((const u64 *)ctx->packed.p, cur_mask(ctx), ctx->stream_len, nw64, p);
+            const unsigned g1 = grid_for(n_tiles, 1, 256 * 16);
+            if (want_pos) sk_part1_kernel<0, true><<<g1, SK1_THREADS, dig_bytes, ctx->stream>>>((const u64 *)ctx->packed.p, cur_mask(ctx), ctx->stream_len, nw64, p);
+            else if (k == 32) sk_part1_kernel<32, false><<<g1, SK1_THREADS, dig_bytes, ctx->stream>>>((const u64 *)ctx->packed.p, cur_mask(ctx), ctx->stream_len, nw64, p);
+            else sk_part1_kernel<0, false><<<g1, SK1_THREADS, dig_bytes, ctx->stream>>>((const u64 *)ctx->packed.p, cur_mask(ctx), ctx->stream_len, nw64, p);
             t1.stop();
             LazyTimer t2(ctx, "part2", 1);
             // a few blocks per sub-stream, each striding over its tiles (most of cap1 is head-room: one block per tile would be mostly empty blocks)
             const u64 exp_tiles = (u64)(est_rec / (double)nb1) / SK2Q_RCAP + 1;
             const unsigned blocks_per_sub = (unsigned)std::min<u64>(std::max<u64>(exp_tiles / 4, 1), 64);
-            sk_part2_raw16_kernel<<<dim3(blocks_per_sub, (unsigned)nb1), SK_THREADS, 0, ctx->stream>>>(p);
+            if (want_pos) sk_part2_raw16_kernel<true><<<dim3(blocks_per_sub, (unsigned)nb1), SK_THREADS, 0, ctx->stream>>>(p);
+            else sk_part2_raw16_kernel<false><<<dim3(blocks_per_sub, (unsigned)nb1), SK_THREADS, 0, ctx->stream>>>(p);
             t2.stop();
             LazyTimer t3(ctx, "bucket", 2);
-            if (k == 32) sk_bucket_kernel<32><<<grid_for(nb2, 1, 256 * 16), SK_ROLL_THREADS, 0, ctx->stream>>>(p, (u64 *)ctx->dist_keys.p, (u32 *)ctx->dist_counts.p, out_cap);
-            else sk_bucket_kernel<0><<<grid_for(nb2, 1, 256 * 16), SK_ROLL_THREADS, 0, ctx->stream>>>(p, (u64 *)ctx->dist_keys.p, (u32 *)ctx->dist_counts.p, out_cap);
+            const unsigned g3 = grid_for(nb2, 1, 256 * 16);
+            if (want_pos) sk_bucket_kernel<0, true><<<g3, SK_ROLL_THREADS, 0, ctx->stream>>>(p, (u64 *)ctx->dist_keys.p, (u32 *)ctx->dist_counts.p, out_cap, (u32 *)ctx->sk_first.p);
+            else if (k == 32) sk_bucket_kernel<32, false><<<g3, SK_ROLL_THREADS, 0, ctx->stream>>>(p, (u64 *)ctx->dist_keys.p, (u32 *)ctx->dist_counts.p, out_cap, nullptr);
+            else sk_bucket_kernel<0, false><<<g3, SK_ROLL_THREADS, 0, ctx->stream>>>(p, (u64 *)ctx->dist_keys.p, (u32 *)ctx->dist_counts.p, out_cap, nullptr);
             t3.stop();
             HIPCHK(hipGetLastError());
             HIPCHK(hipMemcpyAsync(sc, ctx->d_scalars.p, 72, hipMemcpyDeviceToHost, ctx->stream));
@@ -708,6 +722,7 @@ static int count_superk(pb_ctx *ctx, unsigned k, bool *done)
         if (!forced_b && sc[7] > nb2 / 4) return PB_OK;            // still mostly overflowing at 2^18 buckets: the direct path takes it
         ctx->stage_ms["seg_compact"] = 0.f;
         const bool all_in_lds = sc[7] + sc[8] == 0;                // then h_hist already holds the whole histogram
+        if (want_pos && !all_in_lds) return PB_OK;                 // records that left the LDS path carry no position: the caller takes the probing kernel
         if (!all_in_lds) {
             StageTimer t4(ctx, "seg_compact");                     // (stage name kept for bench.py: flagged buckets through the global table)
             sk_flagged_kernel<<<dim3(grid_for(nb2, 1, 1024), 16), 256, 0, ctx->stream>>>(p);

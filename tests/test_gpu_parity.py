@@ -417,10 +417,14 @@ def test_exchange_and_merge_over_rccl_single_rank(gpu, oracle_built):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("path", ["direct", "superk"])
 @pytest.mark.parametrize("mem_bytes,cutoff", [(1 << 20, 1), (1 << 20, 2), (3 << 20, 1), (10 ** 9, 2)])
-def test_kmer_occ_bin_byte_exact_layout(mem_bytes, cutoff, gpu, oracle_built, tmp_path):
+def test_kmer_occ_bin_byte_exact_layout(mem_bytes, cutoff, path, gpu, oracle_built, tmp_path, monkeypatch):
     """CT8: PREFIX_kmer_occ.bin byte-identical to the -t 1 reference layout.  Small -m values make the 1024 stripe tables
-    tiny (64 / 128 slots), so the 32-probe limit, the spill passes and the iterateTimes increments are all exercised."""
+    tiny (64 / 128 slots), so the 32-probe limit, the spill passes and the iterateTimes increments are all exercised.
+    The first occurrence of every k-mer comes from the probing kernel after a direct pass, and from the position-carrying
+    super-k-mer pass (sk_*<POS>) after a super-k-mer pass."""
+    monkeypatch.setitem(GpuCounter.default_options, "count_path", COUNT_PATH[path])
     from platanus_b_amd import synth
     r1, r2 = synth.make_reads(40_000, 40, seed=12, n_rate=0.001)
     codes = np.concatenate([r1, r2])
