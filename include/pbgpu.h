@@ -181,6 +181,23 @@ int pb_graph_fetch_nodes(pb_ctx *ctx, uint32_t *idx, uint32_t *meta, uint32_t *c
 int pb_graph_fetch_chain_records(pb_ctx *ctx, uint32_t *len, uint64_t *sum, uint32_t *end_a, uint32_t *end_b, uint32_t *root,
                                  uint64_t *seq_woff, uint64_t *seq);
 
+/* ---- graph cleaning: the order-independent decisions as node-parallel kernels -------------------------------- */
+/* cutBranch (graph.h:829-926) and, when coverage_cut != 0, deleteErroneousStraightNode (graph.h:2032-2082) over the live nodes of the
+ * caller's graph: straight i has head / tail k-mer (strand-specific, W words each, word 0 least significant), length (k-mers), coverage
+ * and out flags (left nibble << 4 | right nibble, one-hot); tail_entry_* are the entries of rightStraightTable as the caller holds them
+ * (tail key -> straight index); junction j has key, coverage and out flags.  decision[i]: bit 0 = cutBranch
+ * deletes straight i (a tip of length <= k hanging on a junction whose other neighbours on that side reach more than
+ * coverage / branch_threshold), bit 1 = the erroneous-node rule does (coverage < coverage_cut and length < length_cut, not cut as a tip).
+ * The caller applies the deletions in its container order (findStraightHead / findStraightTail / junctionTable look-ups of graph.h:194-219
+ * are done on the device through one table of tagged keys).  Order-independent for branch_threshold < 1 only. */
+int pb_nodes_clean_decide(pb_ctx *ctx, unsigned k, uint64_t n_straight, const uint64_t *head_keys, const uint64_t *tail_keys, const uint64_t *length,
+                          const uint16_t *coverage, const uint8_t *out, uint64_t n_tail_entries, const uint64_t *tail_entry_keys, const uint32_t *tail_entry_ids,
+                          uint64_t n_junction, const uint64_t *junction_keys, const uint16_t *jcoverage, const uint8_t *jout, double branch_threshold,
+                          uint64_t length_cut, uint64_t coverage_cut, uint8_t *decision);
+/* crushBubble's pairwiseAlignment (graph.h:712-746) for n_pairs pairs of base strings (codes 0..3): pair p = bases[offsets[2p] .. offsets[2p+1])
+ * against bases[offsets[2p+1] .. offsets[2p+2]); dist[p] = unit-cost edit distance. */
+int pb_edit_distances(pb_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, uint64_t n_pairs, uint64_t *dist);
+
 /* ---- multi-k rounds (assemble.cpp:392-498) ------------------------------------------------------------------- */
 /* saveEdgeKmer + pickupReadMatchedEdgeKmer (graph.h:1877-1939, counter.h:869-910): keep a read iff one of its N-free
  * k-mers (k = the finished graph's k) is among edge_keys[n_edge*W] (canonical).  Cumulative like the reference's readFP:

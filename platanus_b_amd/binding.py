@@ -84,6 +84,8 @@ def load_library() -> C.CDLL:
     lib.pb_count_considering_contigs.argtypes = [vp, C.c_uint, vp, u64p, u64p]
     lib.pb_occ_table_load.argtypes = [vp, C.c_uint, vp, vp, C.c_uint64]
     lib.pb_occ_lookup.argtypes = [vp, vp, vp, C.c_uint64, vp]
+    lib.pb_nodes_clean_decide.argtypes = [vp, C.c_uint, C.c_uint64, vp, vp, vp, vp, vp, C.c_uint64, vp, vp, C.c_uint64, vp, vp, vp, C.c_double, C.c_uint64, C.c_uint64, vp]
+    lib.pb_edit_distances.argtypes = [vp, vp, vp, C.c_uint64, vp]
     _lib = lib
     return lib
 
@@ -322,6 +324,26 @@ class GpuCounter:
         out = np.zeros(max(int(o[-1] - o[0]), 1), dtype=np.uint16)
         self._chk(self.lib.pb_occ_lookup(self.h, b.ctypes.data, o.ctypes.data, len(o) - 1, out.ctypes.data))
         return out[:int(o[-1] - o[0])]
+
+    # ---- node-parallel cleaning decisions (graph.h:829-926, 2032-2082, 712-746) ----
+    def nodes_clean_decide(self, k, head, tail, length, cov, out, tkeys, tids, jkeys, jcov, jout, branch_th, length_cut=0, coverage_cut=0):
+        a = lambda x, t: np.ascontiguousarray(x, dtype=t)
+        head, tail, tkeys, jkeys = a(head, np.uint64), a(tail, np.uint64), a(tkeys, np.uint64), a(jkeys, np.uint64)
+        length, cov, out = a(length, np.uint64), a(cov, np.uint16), a(out, np.uint8)
+        tids, jcov, jout = a(tids, np.uint32), a(jcov, np.uint16), a(jout, np.uint8)
+        dec = np.zeros(max(len(length), 1), dtype=np.uint8)
+        self._chk(self.lib.pb_nodes_clean_decide(self.h, k, len(length), head.ctypes.data, tail.ctypes.data, length.ctypes.data, cov.ctypes.data, out.ctypes.data,
+                                                 len(tids), tkeys.ctypes.data, tids.ctypes.data, len(jcov), jkeys.ctypes.data, jcov.ctypes.data, jout.ctypes.data,
+                                                 float(branch_th), int(length_cut), int(coverage_cut), dec.ctypes.data))
+        return dec[:len(length)]
+
+    def edit_distances(self, bases: np.ndarray, offsets: np.ndarray) -> np.ndarray:
+        b = np.ascontiguousarray(bases, dtype=np.uint8)
+        o = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = (len(o) - 1) // 2
+        d = np.zeros(max(n, 1), dtype=np.uint64)
+        self._chk(self.lib.pb_edit_distances(self.h, b.ctypes.data, o.ctypes.data, n, d.ctypes.data))
+        return d[:n]
 
     def kernel_ms(self, stage: str) -> float:
         ms = C.c_float()

@@ -142,6 +142,7 @@ struct pb_ctx {
     DevBuf index_table;                 // retained key -> index + 1
     u64 index_table_cap = 0;
     DevBuf node_mark, node_idx, node_rec; // compact export of the k-mers the host replay touches
+    DevBuf node_work, node_table;         // node-parallel cleaning decisions (node_kernels.inc)
     u64 n_nodes = 0, node_cap_hint = 0;
     DevBuf nmask_cur, alive, d_read_start;   // filtered read set: working mask copy, per-read flag, stream starts
     std::vector<u64> read_start;        // host copy: stream position of every read + final sentinel (= stream_len)
@@ -292,7 +293,7 @@ void pb_destroy(pb_ctx *ctx)
     release(ctx->packed); release(ctx->nmask); release(ctx->table); release(ctx->d_hist); release(ctx->d_scalars);
     release(ctx->ret_keys); release(ctx->ret_counts); release(ctx->exp_keys); release(ctx->exp_counts); release(ctx->merge_table);
     release(ctx->dist_keys); release(ctx->dist_counts); release(ctx->part_pos1); release(ctx->part_pos2); release(ctx->sk_first); release(ctx->part_bucket1); release(ctx->part_bucket2); release(ctx->part_meta); release(ctx->part_spill);
-    release(ctx->index_table); release(ctx->node_mark); release(ctx->node_idx); release(ctx->node_rec); release(ctx->nmask_cur); release(ctx->alive); release(ctx->d_read_start);
+    release(ctx->node_work); release(ctx->node_table); release(ctx->index_table); release(ctx->node_mark); release(ctx->node_idx); release(ctx->node_rec); release(ctx->nmask_cur); release(ctx->alive); release(ctx->d_read_start);
     release(ctx->contig_packed); release(ctx->contig_mask); release(ctx->ctable);
     release(ctx->chain_work); release(ctx->chain_rec); release(ctx->chain_seq);
     release(ctx->layout_work); release(ctx->layout_slots); release(ctx->layout_out); release(ctx->scan_sums); release(ctx->slot_blk);
@@ -1163,4 +1164,5 @@ int pb_merge_end(pb_ctx *ctx, uint64_t *occ_hist, uint64_t *max_occ, uint64_t *n
 #include "graph_multik.inc"
 #include "chains.inc"
 #include "kmer_occ_layout.inc"
+#include "node_kernels.inc"
 #include "dist.inc"

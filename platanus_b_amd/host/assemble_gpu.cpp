@@ -82,6 +82,22 @@ struct Driver {
         creator.join();
         if (create_rc != PB_OK) throw GpuError(create_rc, std::string("libpbgpu: ") + pb_last_error(nullptr));
         if (dist()) chk(pb_dist_attach(ctx, opt.shared, opt.rank, opt.world, opt.rccl ? 1 : 0));
+        hook(std::get<0>(graphs)); hook(std::get<1>(graphs)); hook(std::get<2>(graphs)); hook(std::get<3>(graphs)); hook(std::get<4>(graphs));
+    }
+    // the order-independent decisions of the cleaning steps are taken on the device (node_kernels.inc); the graph applies them
+    template <int W> void hook(Graph<W> &g)
+    {
+        g.clean_decide = [this](unsigned kk, u64 n_s, const u64 *head, const u64 *tail, const u64 *length, const u16 *cov, const uint8_t *out, u64 n_t, const u64 *tkeys,
+                                const uint32_t *tids, u64 n_j, const u64 *jkeys, const u16 *jcov, const uint8_t *jout, double th, u64 len_cut, u64 cov_cut, uint8_t *dec) {
+            static_assert(sizeof(u64) == sizeof(uint64_t), "key words are 64-bit");
+            chk(pb_nodes_clean_decide(ctx, kk, n_s, (const uint64_t *)head, (const uint64_t *)tail, (const uint64_t *)length, cov, out, n_t, (const uint64_t *)tkeys, tids, n_j,
+                                      (const uint64_t *)jkeys, jcov, jout, th, len_cut, cov_cut, dec));
+            return true;
+        };
+        g.edit_distances = [this](const uint8_t *bases, const u64 *offsets, u64 n_pairs, u64 *dist_out) {
+            chk(pb_edit_distances(ctx, bases, (const uint64_t *)offsets, n_pairs, (uint64_t *)dist_out));
+            return true;
+        };
     }
     bool dist() const { return opt.world > 1; }    // N ranks on this run: the table is merged over them before every graph stage
     bool writer() const { return opt.rank == 0; }  // every rank computes the same graph; rank 0 writes the files

@@ -49,6 +49,17 @@ static void merge_run(pb_ctx *ctx, const MergeOptions &opt, const MergeContigs &
     Graph<W> g;
     g.set_k(k);
     g.set_thresholds(atof(opt.bubble.c_str()), opt.branch);
+    // the order-independent decisions of cutBranch / crushBubble are taken on the device (node_kernels.inc), as in `assemble`
+    g.clean_decide = [&](unsigned kk, u64 n_s, const u64 *head, const u64 *tail, const u64 *length, const u16 *cov, const uint8_t *out, u64 n_t, const u64 *tkeys,
+                         const uint32_t *tids, u64 n_j, const u64 *jkeys, const u16 *jcov, const uint8_t *jout, double th, u64 len_cut, u64 cov_cut, uint8_t *dec) {
+        chk(pb_nodes_clean_decide(ctx, kk, n_s, (const uint64_t *)head, (const uint64_t *)tail, (const uint64_t *)length, cov, out, n_t, (const uint64_t *)tkeys, tids, n_j,
+                                  (const uint64_t *)jkeys, jcov, jout, th, len_cut, cov_cut, dec));
+        return true;
+    };
+    g.edit_distances = [&](const uint8_t *b, const u64 *offsets, u64 n_pairs, u64 *dist_out) {
+        chk(pb_edit_distances(ctx, b, (const uint64_t *)offsets, n_pairs, (uint64_t *)dist_out));
+        return true;
+    };
     make_initial_from_chains(g, in, cs);
     g.cut_branch_iterative(verbose);
     g.crush_bubble_iterative(avg_cov, verbose);

@@ -22,6 +22,8 @@
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
+#include <functional>
+#include <map>
 #include <vector>
 
 namespace pbh {
@@ -147,6 +149,14 @@ struct Graph {
     std::unordered_map<K, Straight, KeyHash<W>> left;            // leftStraightTable (key = head k-mer)
     std::unordered_map<K, Straight *, KeyHash<W>> right;         // rightStraightTable (key = tail k-mer)
     std::vector<ContigRecord> bubbles;                           // bubbleFP of the last crush_bubble_iterative (graph.h:661-668)
+
+    // Device hooks (set by the GPU build's driver; empty in the oracle, which then runs the reference's sequential loops below).
+    // clean_decide: include/pbgpu.h pb_nodes_clean_decide on the live nodes; edit_distances: pb_edit_distances.  Both return false
+    // when the device call was not made (the host loop takes over).
+    std::function<bool(unsigned k, u64 n_s, const u64 *head, const u64 *tail, const u64 *length, const u16 *cov, const uint8_t *out, u64 n_t, const u64 *tkeys,
+                       const uint32_t *tids, u64 n_j, const u64 *jkeys, const u16 *jcov, const uint8_t *jout, double branch_th, u64 length_cut, u64 coverage_cut,
+                       uint8_t *decision)> clean_decide;
+    std::function<bool(const uint8_t *bases, const u64 *offsets, u64 n_pairs, u64 *dist)> edit_distances;
 
     void set_k(unsigned kk) { k = kk; }
     void set_thresholds(double bubble, double branch) { bubble_th = bubble; branch_th = branch; }
@@ -324,9 +334,90 @@ struct Graph {
         }
     }
 
+    // cutBranch (+ deleteErroneousStraightNode when coverage_cut != 0) with the decisions taken on the device (node_kernels.inc): the live
+    // nodes go over in container order, the deletions are applied in container order.  Returns false if the device was not used.
+    bool clean_pass_device(u64 length_cut, u64 coverage_cut, u64 &num_cut, u64 &num_err)
+    {
+        if (!clean_decide || !(branch_th < 1.0)) return false;       // (>= 1: two tips of one junction may delete each other: order matters)
+        std::vector<u64> head, tail, len, tkeys, jkeys;
+        std::vector<u16> cov, jcov;
+        std::vector<uint8_t> out, jout, dec;
+        std::vector<uint32_t> tids;
+        std::unordered_map<const Straight *, uint32_t> id_of;
+        std::vector<typename std::unordered_map<K, Straight, KeyHash<W>>::iterator> its;
+        for (auto it = left.begin(), end = left.end(); it != end; ++it) {
+            const Straight &st = it->second;
+            if (st.coverage == 65535) continue;
+            id_of[&st] = (uint32_t)its.size();
+            its.push_back(it);
+            const K t = tail_of(st);
+            for (int w = 0; w < W; ++w) { head.push_back(it->first.w[w]); tail.push_back(t.w[w]); }
+            len.push_back(st.length);
+            cov.push_back(st.coverage);
+            out.push_back(st.out);
+        }
+        if (its.empty()) return false;
+        for (auto &e : right) {                                       // rightStraightTable as it stands (an entry may point to a straight with another tail)
+            if (e.second->coverage == 65535) continue;
+            auto f = id_of.find(e.second);
+            if (f == id_of.end()) continue;
+            for (int w = 0; w < W; ++w) tkeys.push_back(e.first.w[w]);
+            tids.push_back(f->second);
+        }
+        for (auto &e : junctions) {
+            if (e.second.coverage == 65535) continue;
+            for (int w = 0; w < W; ++w) jkeys.push_back(e.first.w[w]);
+            jcov.push_back(e.second.coverage);
+            jout.push_back(e.second.out);
+        }
+        dec.assign(its.size(), 0);
+        if (!clean_decide(k, its.size(), head.data(), tail.data(), len.data(), cov.data(), out.data(), tids.size(), tkeys.data(), tids.data(), jcov.size(),
+                          jkeys.data(), jcov.data(), jout.data(), branch_th, length_cut, coverage_cut, dec.data()))
+            return false;
+        num_cut = num_err = 0;
+        for (size_t i = 0; i < its.size(); ++i) {                     // graph.h:882-883 / 913-914
+            if (!(dec[i] & 1)) continue;
+            Straight *st = &its[i]->second;
+            if (st->out >> 4) {
+                Junction *jn = find_junction(pred(its[i]->first, flag2base(st->out >> 4)));
+                jn->out ^= 1u << st->get(st->length - 1);
+            } else {
+                K jk;
+                for (unsigned j = 1; j < k; ++j) jk.set(j, st->get(j - 1));
+                jk.set(0, flag2base(st->out & 0xf));
+                Junction *jn = find_junction(jk);
+                jn->out ^= 1u << (4 + st->get(k - 1));
+            }
+            delete_straight(*st);
+            ++num_cut;
+        }
+        for (size_t i = 0; i < its.size(); ++i) {                     // graph.h:2050-2066
+            if (!(dec[i] & 2)) continue;
+            const Straight &st = its[i]->second;
+            if (st.out >> 4) {
+                Junction *jn = find_junction(pred(its[i]->first, flag2base(st.out >> 4)));
+                if (jn) jn->out ^= 1u << st.get(st.length - 1);
+            }
+            if (st.out & 0xf) {
+                K key;
+                for (unsigned j = 0; j < k - 1; ++j) key.set(j + 1, st.get(j));
+                key.set(0, flag2base(st.out & 0xf));
+                Junction *jn = find_junction(key);
+                if (jn) jn->out ^= 1u << (4 + st.get(k - 1));
+            }
+            delete_straight(st);
+            ++num_err;
+        }
+        return true;
+    }
+
     // graph.h:829-926 (single thread)
     u64 cut_branch()
     {
+        {
+            u64 nc = 0, ne = 0;
+            if (clean_pass_device(0, 0, nc, ne)) return nc;
+        }
         u64 num_delete = 0;
         for (auto it = left.begin(), end = left.end(); it != end; ++it) {
             Straight *st = &it->second;
@@ -534,8 +625,12 @@ struct Graph {
         u64 total = 0, n;
         if (verbose) std::cerr << "removing erroneous nodes..." << std::endl;
         do {
-            n = cut_branch();
-            n += delete_erroneous(length_cut, coverage_cut);
+            u64 nc = 0, ne = 0;
+            if (coverage_cut && clean_pass_device(length_cut, coverage_cut, nc, ne)) n = nc + ne;       // both decisions in one device pass
+            else {
+                n = cut_branch();
+                n += delete_erroneous(length_cut, coverage_cut);
+            }
             if (verbose) std::cerr << "NUM_REMOVED_NODES=" << n << std::endl;
             concatinate_nodes();
             total += n;
@@ -591,6 +686,36 @@ struct Graph {
         Straight *st[4], *mx[4];
         u16 cov_th = static_cast<u16>(std::min(static_cast<u64>(avg_cov * 1.5 + 0.5), static_cast<u64>(65535)));
         if (avg_cov >= 65535) cov_th = 65535;
+        // Device: the edit distances of ALL pairs of branches that leave one junction and meet again in one junction, at once (the
+        // sequences do not change while bubbles are crushed; nodes only disappear, so this is a superset of what the loop below asks for)
+        std::map<std::pair<const Straight *, const Straight *>, u64> known;
+        if (edit_distances) {
+            std::vector<uint8_t> bases;
+            std::vector<u64> offs{0};
+            std::vector<std::pair<const Straight *, const Straight *>> pairs;
+            for (auto it = junctions.begin(), end = junctions.end(); it != end; ++it) {
+                Junction *root = &it->second;
+                if (root->coverage == 65535 || flag_count(root->out & 0x0f) < 2) continue;
+                for (unsigned b = 0; b < 4; ++b) { st[b] = nullptr; jn[b] = nullptr; }
+                search_bubble(root, jn, st, it->first);
+                for (unsigned b1 = 0; b1 < 3; ++b1)
+                    for (unsigned b2 = b1 + 1; b2 < 4; ++b2) {
+                        if (st[b1] == nullptr || st[b2] == nullptr || jn[b1] == nullptr || jn[b1] != jn[b2]) continue;
+                        if (std::min(st[b1]->length, st[b2]->length) + 1 <= k) continue;
+                        for (const Straight *sx : {st[b1], st[b2]}) {                  // graph.h:716-717,726: the part in front of the shared k - 1 bases
+                            const u64 l = sx->length - k + 1;
+                            for (u64 m = 0; m < l; ++m) bases.push_back((uint8_t)sx->get(sx->length - 1 - m));
+                            offs.push_back(bases.size());
+                        }
+                        pairs.push_back({st[b1], st[b2]});
+                    }
+            }
+            if (!pairs.empty()) {
+                std::vector<u64> dist(pairs.size());
+                if (edit_distances(bases.data(), offs.data(), pairs.size(), dist.data()))
+                    for (size_t i = 0; i < pairs.size(); ++i) known[pairs[i]] = dist[i];
+            }
+        }
         for (auto it = junctions.begin(), end = junctions.end(); it != end; ++it) {
             Junction *root = &it->second;
             if (root->coverage == 65535 || flag_count(root->out & 0x0f) < 2) continue;
@@ -606,7 +731,8 @@ struct Graph {
                         if (cluster[b2] == b2) cluster[b2] = cluster[b1]; else cluster[b1] = cluster[b2];
                         continue;
                     }
-                    if (pairwise_alignment(st[b1], st[b2]) > ath) continue;
+                    const auto kn = known.find({st[b1], st[b2]});
+                    if ((kn != known.end() ? kn->second : pairwise_alignment(st[b1], st[b2])) > ath) continue;
                     if (cluster[b2] == b2) cluster[b2] = cluster[b1]; else cluster[b1] = cluster[b2];
                 }
             }

@@ -255,3 +255,107 @@ def test_occurrence_lookup(k):
             want[int(base) + p] = table.get(_canon(x, k)[0], 0)
     assert want.any()
     assert np.array_equal(got, want)
+
+
+def test_edit_distances_against_plain_dp():
+    """pb_edit_distances = crushBubble's pairwiseAlignment (graph.h:712-746): unit-cost edit distance of pairs of base strings."""
+    rng = np.random.default_rng(5)
+    seqs = []
+    for _ in range(150):
+        a = rng.integers(0, 4, int(rng.integers(1, 400))).astype(np.uint8)
+        b = a.copy()
+        for _ in range(int(rng.integers(0, 12))):                     # substitutions, insertions, deletions
+            kind, p = int(rng.integers(0, 3)), int(rng.integers(0, max(len(b), 1)))
+            if kind == 0 and len(b):
+                b[p] = (b[p] + 1 + rng.integers(0, 3)) & 3
+            elif kind == 1:
+                b = np.insert(b, p, rng.integers(0, 4))
+            elif len(b) > 1:
+                b = np.delete(b, p)
+        if rng.random() < 0.2:
+            b = rng.integers(0, 4, int(rng.integers(1, 300))).astype(np.uint8)
+        seqs += [a, b.astype(np.uint8)]
+    off = np.concatenate([[0], np.cumsum([len(s) for s in seqs])]).astype(np.uint64)
+    g = GpuCounter(0)
+    got = g.edit_distances(np.concatenate(seqs), off)
+    for p in range(len(seqs) // 2):
+        a, b = seqs[2 * p], seqs[2 * p + 1]
+        prev = list(range(len(b) + 1))
+        for m in range(len(a)):
+            cur = [m + 1] + [0] * len(b)
+            for n in range(len(b)):
+                cur[n + 1] = prev[n] if a[m] == b[n] else min(prev[n], prev[n + 1], cur[n]) + 1
+            prev = cur
+        assert int(got[p]) == prev[len(b)], p
+
+
+@pytest.mark.parametrize("k", [21, 32, 45, 100])
+def test_node_cleaning_decisions_against_plain_loops(k):
+    """pb_nodes_clean_decide on random node sets: junctions with tips, real branches and junction-junction links on both sides; the
+    checker restates cutBranch (graph.h:829-926) and deleteErroneousStraightNode's predicate (graph.h:2048-2049) with dictionaries."""
+    rng = np.random.default_rng(k)
+    W = words_for_k(k)
+    mask = (1 << (2 * k)) - 1
+    rk = lambda: int.from_bytes(rng.bytes(8 * W), "little") & mask
+    succ = lambda x, b: ((x << 2) | b) & mask
+    pred = lambda x, b: (x >> 2) | (b << (2 * (k - 1)))
+    junctions, straights = {}, []                                     # key -> [cov, out]; dict(head, tail, length, cov, out)
+    for _ in range(400):
+        jk = rk()
+        jout = 0
+        for side in (0, 1):                                           # 0: right links (heads of straights leaving it), 1: left links (tails)
+            for b in rng.permutation(4)[:int(rng.integers(0, 4))]:
+                b = int(b)
+                nk = succ(jk, b) if side == 0 else pred(jk, b)
+                kind = rng.random()
+                jout |= 1 << (b if side == 0 else b + 4)
+                if kind < 0.15:
+                    junctions.setdefault(nk, [int(rng.integers(1, 200)), 0])     # a junction as neighbour
+                    continue
+                length = int(rng.integers(1, 3 * k)) if kind < 0.7 else int(rng.integers(1, k + 1))
+                other = 0 if rng.random() < 0.6 else 1 << int(rng.integers(0, 4))   # a tip has nothing on its far side
+                base = 1 << (jk >> (2 * (k - 1)) if side == 0 else jk & 3)          # flag of the base that leads back to the junction
+                if side == 0:
+                    straights.append(dict(head=nk, tail=rk(), length=length, cov=int(rng.integers(1, 120)), out=(base << 4) | other))
+                else:
+                    straights.append(dict(head=rk(), tail=nk, length=length, cov=int(rng.integers(1, 120)), out=(other << 4) | base))
+        junctions[jk] = [int(rng.integers(1, 200)), jout]
+    head_of = {s["head"]: i for i, s in enumerate(straights)}
+    tail_tab = {s["tail"]: i for i, s in enumerate(straights)}
+    assert len(head_of) == len(straights) and len(tail_tab) == len(straights)
+    jlist = list(junctions.items())
+    th, len_cut, cov_cut = 0.5, 2 * k, 30
+
+    def words(x):
+        return [(x >> (64 * w)) & 0xFFFFFFFFFFFFFFFF for w in range(W)]
+
+    want = []
+    for i, s in enumerate(straights):
+        cut = False
+        lf, rf = s["out"] >> 4, s["out"] & 15
+        if s["length"] <= k and (lf != 0) != (rf != 0):
+            left = lf != 0
+            b0 = {1: 0, 2: 1, 4: 2, 8: 3}[lf if left else rf]
+            jk = pred(s["head"], b0) if left else succ(s["tail"], b0)
+            if jk in junctions:
+                mx = 0
+                for b in range(4):
+                    if not junctions[jk][1] & (1 << (b if left else b + 4)):
+                        continue
+                    nk = succ(jk, b) if left else pred(jk, b)
+                    t = (head_of if left else tail_tab).get(nk)
+                    if t is not None and t != i and straights[t]["cov"] > mx:
+                        mx = straights[t]["cov"]
+                        continue
+                    if nk in junctions and junctions[nk][0] > mx:
+                        mx = junctions[nk][0]
+                cut = not (s["cov"] > mx * th)
+        err = (not cut) and s["cov"] < cov_cut and s["length"] < len_cut
+        want.append((1 if cut else 0) | (2 if err else 0))
+    g = GpuCounter(0)
+    got = g.nodes_clean_decide(k, [w for s in straights for w in words(s["head"])], [w for s in straights for w in words(s["tail"])],
+                               [s["length"] for s in straights], [s["cov"] for s in straights], [s["out"] for s in straights],
+                               [w for s in straights for w in words(s["tail"])], list(range(len(straights))),
+                               [w for jk, _ in jlist for w in words(jk)], [v[0] for _, v in jlist], [v[1] for _, v in jlist], th, len_cut, cov_cut)
+    assert sum(1 for w_ in want if w_ & 1) > 20 and sum(1 for w_ in want if w_ & 2) > 20
+    assert list(got) == want
