@@ -164,7 +164,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--genome", type=int, default=GENOME, help="override the workload size (development only)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline, the end-to-end CLI runs and the shard shapes (profiling runs)")
+    ap.add_argument("--shard-shapes-only", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
+    if a.shard_shapes_only:
+        print(json.dumps(shard_shapes()))
+        return
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -306,7 +310,10 @@ def main():
             finally:
                 subprocess.run(["rm", "-rf", tmp])
             try:
-                out["shard_shapes"] = shard_shapes()
+                # in a process of its own: the kernel statistics of THIS process then hold the timed workload only (rocprofv3 writes one
+                # summary per process, and profiles/ quotes the average launch duration of the counting kernels from it)
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--shard-shapes-only"], capture_output=True, text=True, timeout=900)
+                out["shard_shapes"] = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": r.stderr[-500:]}
             except Exception as e:
                 out["shard_shapes"] = {"error": str(e)}
         print(json.dumps(out))
