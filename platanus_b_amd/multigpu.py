@@ -102,15 +102,15 @@ def gather_retained(dist, torch, keys: np.ndarray, counts: np.ndarray, W: int):
     return gk[order], gc[order]
 
 
-def exchange_and_merge(g, dist, world: int, rank: int):
-    """g: GpuCounter that has just counted this rank's reads.  After the call g's table is this rank's owner
+def exchange_and_merge(g, dist, world: int, rank: int, split: bool = True):
+    """g: GpuCounter that has just counted this rank's reads.  split=False: every record travels with a 32-bit count (A/B runs).  After the call g's table is this rank's owner
     shard of the global table and g.occ_hist / g.max_occ / g.n_distinct describe the GLOBAL distribution."""
     import torch
     from .binding import PB_OCC_BINS, words_for_k
     lib, h = g.lib, g.h
     W = words_for_k(g.k)
     dev = torch.device("cuda", torch.cuda.current_device())
-    if os.environ.get("PB_EXCHANGE") == "v1":          # development / A-B: every record with a 32-bit count
+    if not split:                                      # every record with a 32-bit count
         part = (C.c_uint64 * world)()
         g._chk(lib.pb_export_begin(h, world, part))
         send = [int(x) for x in part]
