@@ -693,6 +693,14 @@ static int count_superk(pb_ctx *ctx, unsigned k, bool *done, bool want_pos = fal
             (void)hipMemcpyFromSymbol(&v[0], HIP_SYMBOL(sk_dbg_probe_iters), 8); (void)hipMemcpyFromSymbol(&v[1], HIP_SYMBOL(sk_dbg_flushes), 8);
             (void)hipMemcpyFromSymbol(&v[2], HIP_SYMBOL(sk_dbg_parked), 8); (void)hipMemcpyFromSymbol(&v[3], HIP_SYMBOL(sk_dbg_steps), 8);
             (void)hipMemcpyFromSymbol(&v[4], HIP_SYMBOL(sk_dbg_inserts), 8);
+            {
+                unsigned long long c1[12], t1 = 0;
+                (void)hipMemcpyFromSymbol(c1, HIP_SYMBOL(sk1_dbg_cyc), 96);
+                for (int i = 0; i < 12; ++i) t1 += c1[i];
+                static const char *n1[12] = {"stage the tile", "barrier 1", "hashes + store", "barrier 2", "a8 (neighbours, doubling, store)", "barrier 3", "window minima (3 x 17 reads)",
+                                             "barrier 4", "run starts + digit histogram", "rank scan (2 barriers)", "digit scan + record build", "barrier + copy-out"};
+                for (int i = 0; i < 12; ++i) fprintf(stderr, "[pbgpu]   part1 wave cycles %-34s %5.1f %%\n", n1[i], 100.0 * (double)c1[i] / (double)t1);
+            }
             unsigned long long cyc[12];
             (void)hipMemcpyFromSymbol(cyc, HIP_SYMBOL(sk_dbg_cyc), 96);
             unsigned long long tot = 0;
