@@ -7,9 +7,11 @@ One step = one pass of Counter::makeKmerReadDistributionMT's device equivalent (
 canonical k-mer extraction + hashing of every read window, occurrenceDistribution histogram) over this
 rank's resident reads, k = 32.  Workload at N=1 = BASELINE.json configs[1]: 5 Mbp synthetic genome,
 100x PE150, 0.5 % substitutions, occurrence table only.  For N>1 every rank holds a full configs[1]-sized
-range of read pairs of a 100*N x set (weak scaling; at N=8 that is the shape of configs[3]) and each step
-ends with the owner exchange of (key,count) records over RCCL (torch.distributed all_to_all) + owner-side
-merge + all-reduce of the histogram.
+range of read pairs of a 100*N x set (weak scaling; at N=8 that is the shape of configs[3]).  N > 1 step
+(--exchange records, the default for power-of-two N): every rank cuts its reads into run records grouped by
+the owner of their minimizer bucket, ONE all_to_all over RCCL moves them, every rank counts what it received,
+all-reduce of the histogram.  --exchange counts: count locally, exchange (key,count) records by stripe owner,
+owner-side merge.
 
 Reads are packed on the device before the timed region (inputs resident in HBM).  The JSON line carries
 `roofline` (HBM, algorithmic bytes 12.25 B per k-mer instance at k=32: SURVEY.md 8(d)), `cpu_baseline`
@@ -164,6 +166,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--genome", type=int, default=GENOME, help="override the workload size (development only)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline, the end-to-end CLI runs and the shard shapes (profiling runs)")
+    ap.add_argument("--exchange", choices=["records", "counts"], default="records",
+                    help="N > 1 step: 'records' = run records by owner, ONE all_to_all, counted on arrival (power-of-two N); 'counts' = count, "
+                         "export (key,count) by owner, all_to_all, owner-side merge")
     ap.add_argument("--shard-shapes-only", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
     if a.shard_shapes_only:
@@ -187,7 +192,8 @@ def main():
 
     from platanus_b_amd import synth
     from platanus_b_amd.binding import GpuCounter
-    from platanus_b_amd.multigpu import exchange_and_merge
+    from platanus_b_amd.multigpu import count_exchanging_records, exchange_and_merge
+    by_records = world > 1 and a.exchange == "records" and world & (world - 1) == 0
 
     # this rank's range of read pairs: rank r of a (COVERAGE*world)x set holds pairs [r*P, (r+1)*P)
     pairs_per_rank = int(a.genome * COVERAGE) // (2 * READ_LEN)
@@ -203,9 +209,12 @@ def main():
     n_reads, n_bases = g.reads_info()
 
     def step():
-        g.make_kmer_read_distribution(K)
-        if world > 1:
-            exchange_and_merge(g, dist, world, rank)
+        if by_records:
+            count_exchanging_records(g, dist, world, rank, K)
+        else:
+            g.make_kmer_read_distribution(K)
+            if world > 1:
+                exchange_and_merge(g, dist, world, rank)
 
     for _ in range(a.warmup):
         step()
@@ -217,6 +226,13 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
+        if by_records:                       # this rank's kernels: the run records of its reads + scatter / bucket kernel on what it received
+            count_ms.append(g.kernel_ms("part1") + g.kernel_ms("count_records"))
+            init_ms.append(0.0)
+            hist_ms.append(0.0)
+            for st in stage_ms:
+                stage_ms[st].append(g.kernel_ms(st) if st == "part1" else 0.0)
+            continue
         count_ms.append(g.kernel_ms("count"))
         init_ms.append(g.kernel_ms("table_init"))
         hist_ms.append(g.kernel_ms("hist"))
@@ -283,7 +299,8 @@ def main():
             "config": {"workload": f"{a.genome / 1e6:g} Mbp synthetic genome, {COVERAGE * world:.0f}x PE{READ_LEN}, k={K}, "
                                    f"occurrence table only (BASELINE configs[1] per GPU)",
                        "reads_per_gpu": int(n_reads), "kmer_instances_per_gpu": int(instances), "distinct_kmers": int(g.n_distinct),
-                       "parallelism": f"reads range-partitioned over {world} GPU(s)" + (", owner exchange over RCCL" if world > 1 else ""),
+                       "parallelism": f"reads range-partitioned over {world} GPU(s)" + ("" if world == 1 else ", run records exchanged by bucket owner over RCCL "
+                                      "(one all_to_all), counted on arrival" if by_records else ", (key,count) records exchanged by stripe owner over RCCL, owner-side merge"),
                        "torch_distributed": ({"backend": dist.get_backend(), "world_size": dist.get_world_size()} if dist is not None else None),
                        "histogram_identical_to_reference_md5": hist_ok,
                        "inherited_PB_environment": {k_: v for k_, v in os.environ.items() if k_.startswith("PB_")}},

@@ -118,6 +118,22 @@ int pb_merge_end(pb_ctx *ctx, uint64_t *occ_hist, uint64_t *max_occ, uint64_t *n
 int pb_merge_records(pb_ctx *ctx, unsigned k, const void *dev_keys, const void *dev_counts, uint64_t n, uint64_t *occ_hist,
                      uint64_t *max_occ, uint64_t *n_distinct);
 
+/* ---- X1, second design: records exchanged BEFORE they are counted (k <= 32).  The minimizer bucket of a k-mer is a function of the
+ * k-mer, so "owner = top bits of the bucket" partitions the key space like the reference's stripes do.
+ *   pb_sk_bucket_bits       the bucket bits the library would use for `windows` k-mer instances on one GPU (every rank passes the same
+ *                           local_bits, e.g. pb_sk_bucket_bits(max over ranks of the windows a rank will receive))
+ *   pb_sk_owner_records     this rank's reads cut into 16-byte run records grouped by owner; counts[o] = records for owner o
+ *                           (n_owners a power of two >= 2, log2(n_owners) + local_bits <= 20)
+ *   pb_sk_owner_records_copy  the records, owner 0 first, into a caller device buffer (e.g. a torch tensor that then goes through
+ *                           torch.distributed.all_to_all_single)
+ *   pb_sk_count_records     counts the records a rank received (any order): outputs as pb_count's for this rank's share of the keys;
+ *                           afterwards pb_retain / pb_fetch_all / pb_export_* work on it */
+unsigned pb_sk_bucket_bits(uint64_t windows);
+int pb_sk_owner_records(pb_ctx *ctx, unsigned k, unsigned n_owners, unsigned local_bits, uint64_t *counts, uint64_t *n_windows);
+int pb_sk_owner_records_copy(pb_ctx *ctx, void *dev_records);
+int pb_sk_count_records(pb_ctx *ctx, unsigned k, const void *dev_records, uint64_t n_records, unsigned local_bits, uint64_t *occ_hist, uint64_t *max_occ,
+                        uint64_t *n_distinct);
+
 /* ---- E2: N ranks of one node on one run (configs 4 and 5: reads range-partitioned over the GPUs, one merged table for the graph
  * stage and for every later round, assemble.cpp:343-354,449-478).  The launcher calls pb_dist_shared_create BEFORE it forks the ranks
  * (no HIP call inside); every rank then makes its own context and attaches.  All pb_dist_* calls below are collective: every rank

@@ -71,6 +71,11 @@ def load_library() -> C.CDLL:
     lib.pb_merge_end.argtypes = [vp, vp, u64p, u64p]
     lib.pb_merge_records.argtypes = [vp, C.c_uint, vp, vp, C.c_uint64, vp, u64p, u64p]
     lib.pb_kmer_occ_layout.argtypes = [vp, C.c_uint64, C.c_uint, u64p, u64p]
+    lib.pb_sk_bucket_bits.argtypes = [C.c_uint64]
+    lib.pb_sk_bucket_bits.restype = C.c_uint
+    lib.pb_sk_owner_records.argtypes = [vp, C.c_uint, C.c_uint, C.c_uint, u64p, u64p]
+    lib.pb_sk_owner_records_copy.argtypes = [vp, vp]
+    lib.pb_sk_count_records.argtypes = [vp, C.c_uint, vp, C.c_uint64, C.c_uint, vp, u64p, u64p]
     lib.pb_kmer_occ_fetch.argtypes = [vp, vp, vp, vp]
     lib.pb_graph_adjacency.argtypes = [vp, vp, vp]
     lib.pb_graph_chains.argtypes = [vp, u64p, u64p]

@@ -120,6 +120,7 @@ struct pb_ctx {
     CopyPool *copy_pool = nullptr;
     u64 *h_hist = nullptr;              // pinned; filled behind sk_bucket_kernel so that the pass needs one host synchronisation
     bool h_hist_valid = false;
+    u64 sk_owner_cap1 = 0;          // pb_sk_owner_records: records per owner region
     u64 exp_cur[64] = {0};           // start of every owner's segment in the export (pb_export_begin -> pb_export_copy)
     u64 exp2_key_start[128] = {0}, exp2_cnt_start[64] = {0};   // pb_export_split_begin -> pb_export_split_copy
     unsigned exp2_parts = 0;
@@ -613,6 +614,7 @@ static int count_superk(pb_ctx *ctx, unsigned k, bool *done, bool want_pos = fal
         // expected windows per record: a run ends when a smaller m-mer enters the window or the minimizer leaves it -- (w + 1) / 2
         // windows on random sequence; every read start and every unknown base cuts one more
         const double est_rec = (double)windows * 2.0 / (p.w + 1.0) + 2.0 * (double)ctx->n_reads;
+        p.nx = PB_XCD;
         const u64 nb1 = (1ull << p.l1) * PB_XCD, nb2 = 1ull << B;
         p.cap1 = (u64)(est_rec / (double)nb1 * 1.5) + 4096;
         p.cap2 = (u32)std::min<double>(est_rec / (double)nb2 * 3.0 + 256.0, 1e9);   // minimizer sites are few per bucket: sizes vary a lot
@@ -800,6 +802,205 @@ static int sort_retained(pb_ctx *ctx, u64 n)
     HIPCHK(hipGetLastError());
     return tm.stop();
 }
+
+// ---- X1, second design: the records are exchanged BEFORE they are counted -------------------------------------------------
+// The minimizer bucket of a k-mer is a function of the k-mer, so "rank = top bits of the bucket" is a partition of the key space as
+// good as the reference's stripes: every rank cuts ITS reads into run records whose level-1 digit is the owner rank
+// (pb_sk_owner_records), one all-to-all moves the records, and every rank runs the level-1 / level-2 scatter and the bucket
+// kernel on what it received (pb_sk_count_records).  No export, no owner-side merge: copies of a run from different ranks meet in
+// sk_bucket_kernel's record table like copies from different reads.
+static unsigned sk_bits_for(u64 windows)
+{
+    unsigned B = 8;
+    while (((u64)(SK_SLOTS * 3) << B) < windows && B < 18) ++B;
+    return B;
+}
+
+extern "C" {
+
+// bucket bits the super-k-mer pass would use for `windows` k-mer instances on one GPU (all ranks must agree on local_bits below)
+unsigned pb_sk_bucket_bits(uint64_t windows) { return sk_bits_for(windows); }
+
+// Stage 1: run records of this rank's reads, grouped by owner (n_owners a power of two >= 2; owner = top bits of the
+// (log2(n_owners) + local_bits)-bit bucket).  counts[o] = records for owner o (16 bytes each); *n_windows = windows they hold.
+int pb_sk_owner_records(pb_ctx *ctx, unsigned k, unsigned n_owners, unsigned local_bits, uint64_t *counts, uint64_t *n_windows)
+{
+    if (!ctx || !counts || k < 1 || k > 32 || n_owners < 2 || n_owners > PB_MAX_PARTS || (n_owners & (n_owners - 1)) || local_bits < 2 || local_bits > 18)
+        return PB_EINVAL;
+    (void)hipSetDevice(ctx->dev);
+    int rc;
+    if ((rc = ensure(ctx, ctx->d_scalars, 16 * 8)) != PB_OK) return rc;
+    unsigned ob = 0;
+    while ((1u << ob) < n_owners) ++ob;
+    if (ob + local_bits > 20) { ctx->err = "pb_sk_owner_records: owner bits + local bits must not exceed 20 (the record's bucket field)"; return PB_ERANGE; }
+    const u64 lost = (u64)k * ctx->n_reads;
+    const u64 windows = ctx->stream_len > lost + 4096 ? ctx->stream_len - lost : ctx->stream_len;
+    SkParams p;
+    memset(&p, 0, sizeof(p));
+    p.k = k;
+    p.m = k < SK_M ? k : SK_M;
+    p.w = k - p.m + 1;
+    p.B = ob + local_bits;
+    p.l1 = ob;
+    p.l2 = local_bits;
+    p.nx = 1;
+    const double est_rec = (double)windows * 2.0 / (p.w + 1.0) + 2.0 * (double)ctx->n_reads;
+    p.cap1 = (u64)(est_rec / (double)n_owners * 1.5) + 65536;
+    p.cap2 = 0;
+    if ((rc = ensure(ctx, ctx->part_bucket1, (u64)n_owners * p.cap1 * SkStore16::BYTES)) != PB_OK) return rc;
+    if ((rc = ensure(ctx, ctx->part_meta, ((u64)n_owners + 2ull * (1ull << p.B)) * 4)) != PB_OK) return rc;
+    p.spill_cap = 1ull << 16;
+    if ((rc = ensure(ctx, ctx->part_spill, p.spill_cap * SkStore16::BYTES)) != PB_OK) return rc;
+    p.spill = ctx->part_spill.p;
+    p.bucket1 = ctx->part_bucket1.p;
+    p.cursor1 = (u32 *)ctx->part_meta.p;
+    p.cursor2 = p.cursor1 + n_owners;
+    p.flag2 = p.cursor2 + (1ull << p.B);                       // (only written when a record does not fit its owner's region)
+    p.scalars = (u64 *)ctx->d_scalars.p;
+    HIPCHK(hipMemsetAsync(ctx->d_scalars.p, 0, 16 * 8, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->part_meta.p, 0, ((u64)n_owners + 2ull * (1ull << p.B)) * 4, ctx->stream));
+    {
+        StageTimer t1(ctx, "part1");
+        const u64 n_tiles = (ctx->stream_len + SK1_OWN - 1) / SK1_OWN;
+        const size_t dig_bytes = (size_t)3 * 4 * (1u << p.l1);
+        const u64 nw64 = (ctx->stream_len + 63) / 64 + PB_STREAM_PAD_WORDS64;
+        const unsigned g1 = grid_for(n_tiles, 1, 256 * 16);
+        if (ctx->stream_len >= k) {
+            if (k == 32) sk_part1_kernel<32, false><<<g1, SK1_THREADS, dig_bytes, ctx->stream>>>((const u64 *)ctx->packed.p, cur_mask(ctx), ctx->stream_len, nw64, p);
+            else sk_part1_kernel<0, false><<<g1, SK1_THREADS, dig_bytes, ctx->stream>>>((const u64 *)ctx->packed.p, cur_mask(ctx), ctx->stream_len, nw64, p);
+        }
+        HIPCHK(hipGetLastError());
+        if ((rc = t1.stop()) != PB_OK) return rc;
+    }
+    u64 sc[10];
+    std::vector<u32> cur(n_owners);
+    HIPCHK(hipMemcpyAsync(sc, ctx->d_scalars.p, 80, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(cur.data(), p.cursor1, n_owners * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (sc[8] || sc[1]) { ctx->err = "pb_sk_owner_records: an owner's region overflowed (a few minimizers carry most of the input)"; return PB_ERANGE; }
+    for (unsigned o = 0; o < n_owners; ++o) { counts[o] = cur[o]; ctx->exp_cur[o] = cur[o]; }
+    ctx->exp_parts = n_owners;
+    ctx->sk_owner_cap1 = p.cap1;
+    ctx->n_instances = sc[0];
+    if (n_windows) *n_windows = sc[0];
+    return PB_OK;
+}
+
+// the records of pb_sk_owner_records, owner 0 first, into a caller device buffer of sum(counts) * 16 bytes
+int pb_sk_owner_records_copy(pb_ctx *ctx, void *dev_records)
+{
+    if (!ctx || !dev_records || ctx->exp_parts == 0 || ctx->sk_owner_cap1 == 0) return PB_EINVAL;
+    (void)hipSetDevice(ctx->dev);
+    u64 at = 0;
+    for (unsigned o = 0; o < ctx->exp_parts; ++o) {
+        const u64 n = ctx->exp_cur[o];
+        if (n) HIPCHK(hipMemcpyAsync((char *)dev_records + at * 16, (const char *)ctx->part_bucket1.p + (u64)o * ctx->sk_owner_cap1 * 16, n * 16, hipMemcpyDeviceToDevice, ctx->stream));
+        at += n;
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return PB_OK;
+}
+
+// Stage 2: counts the n_records run records in dev_records (this rank's share of every rank's stage 1, any order): level-1 and level-2
+// scatter on the low local_bits bucket bits (the owner bits above them are ignored), bucket kernel, histogram.  Outputs as pb_count's,
+// for THIS rank's share of the key space; afterwards pb_retain / pb_export_* / pb_fetch_all work on it.
+int pb_sk_count_records(pb_ctx *ctx, unsigned k, const void *dev_records, uint64_t n_records, unsigned local_bits, uint64_t *occ_hist, uint64_t *max_occ,
+                        uint64_t *n_distinct)
+{
+    if (!ctx || k < 1 || k > 32 || (n_records && !dev_records) || local_bits < 2 || local_bits > 18) return PB_EINVAL;
+    (void)hipSetDevice(ctx->dev);
+    int rc;
+    ctx->k = k;
+    ctx->W = 1;
+    ctx->n_retained = 0;
+    ctx->n_distinct = 0;
+    if ((rc = ensure(ctx, ctx->d_scalars, 16 * 8)) != PB_OK) return rc;
+    SkParams p;
+    memset(&p, 0, sizeof(p));
+    p.k = k;
+    p.m = k < SK_M ? k : SK_M;
+    p.w = k - p.m + 1;
+    const unsigned B = local_bits;
+    p.B = B;
+    p.l1 = B / 2;
+    p.l2 = B - p.l1;
+    p.nx = PB_XCD;
+    const double est_rec = (double)std::max<u64>(n_records, 1);
+    const u64 nb1 = (1ull << p.l1) * PB_XCD, nb2 = 1ull << B;
+    p.cap1 = (u64)(est_rec / (double)nb1 * 1.5) + 4096;
+    p.cap2 = (u32)std::min<double>(est_rec / (double)nb2 * 3.0 + 256.0, 1e9);
+    // the level-1 sub-streams of this pass must not share storage with the incoming records: part_bucket1 may be the caller's source
+    // (it is not: callers pass their own buffer), so a second buffer is used for them
+    if ((rc = ensure(ctx, ctx->scratch[4], nb1 * p.cap1 * SkStore16::BYTES)) != PB_OK) return rc;
+    if ((rc = ensure(ctx, ctx->part_bucket2, (nb2 * (u64)p.cap2 + 1024) * SkStore16::BYTES)) != PB_OK) return rc;
+    if ((rc = ensure(ctx, ctx->part_meta, (nb1 + 2 * nb2) * 4)) != PB_OK) return rc;
+    p.spill_cap = std::max<u64>((u64)(est_rec / 16), 1ull << 16);
+    if ((rc = ensure(ctx, ctx->part_spill, p.spill_cap * SkStore16::BYTES)) != PB_OK) return rc;
+    p.spill = ctx->part_spill.p;
+    p.bucket1 = ctx->scratch[4].p;
+    p.bucket2 = ctx->part_bucket2.p;
+    p.cursor1 = (u32 *)ctx->part_meta.p;
+    p.cursor2 = p.cursor1 + nb1;
+    p.flag2 = p.cursor2 + nb2;
+    const u64 out_cap = std::min<u64>(std::max<u64>(n_records * SK_RUN_MAXLEN, 1), nb2 * (u64)SK_SLOT_LIMIT);
+    u64 fcap = 1ull << 20;
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        if ((rc = ensure(ctx, ctx->dist_keys, (out_cap + fcap) * 8)) != PB_OK) return rc;
+        if ((rc = ensure(ctx, ctx->dist_counts, (out_cap + fcap) * 4)) != PB_OK) return rc;
+        if ((rc = ensure(ctx, ctx->table, fcap * 16)) != PB_OK) return rc;
+        ctx->table_cap = fcap;
+        p.fallback = TableView<1>{(u64 *)ctx->table.p, fcap - 1};
+        p.scalars = (u64 *)ctx->d_scalars.p;
+        if ((rc = ensure(ctx, ctx->d_hist, 65536 * 8)) != PB_OK) return rc;
+        p.hist = (u64 *)ctx->d_hist.p;
+        HIPCHK(hipMemsetAsync(ctx->d_hist.p, 0, 65536 * 8, ctx->stream));
+        HIPCHK(hipMemsetAsync(ctx->d_scalars.p, 0, 16 * 8, ctx->stream));
+        HIPCHK(hipMemsetAsync(ctx->part_meta.p, 0, (nb1 + 2 * nb2) * 4, ctx->stream));
+        table_init_kernel<1><<<grid_for(fcap * 2, 256, 256 * 32), 256, 0, ctx->stream>>>(p.fallback.slots, fcap);
+        StageTimer tm(ctx, "count_records");
+        if (n_records) {
+            const unsigned gf = (unsigned)std::min<u64>(std::max<u64>(n_records / SK2Q_RCAP / 2, 1), 256 * 12);
+            sk_part2_raw16_kernel<false, true><<<dim3(gf, 1), SK_THREADS, 0, ctx->stream>>>(p, (const uint4 *)dev_records, n_records);
+            const u64 exp_tiles = (u64)(est_rec / (double)nb1) / SK2Q_RCAP + 1;
+            const unsigned blocks_per_sub = (unsigned)std::min<u64>(std::max<u64>(exp_tiles / 4, 1), 64);
+            sk_part2_raw16_kernel<false><<<dim3(blocks_per_sub, (unsigned)nb1), SK_THREADS, 0, ctx->stream>>>(p);
+            const unsigned g3 = grid_for(nb2, 1, 256 * 16);
+            if (k == 32) sk_bucket_kernel<32, false><<<g3, SK_ROLL_THREADS, 0, ctx->stream>>>(p, (u64 *)ctx->dist_keys.p, (u32 *)ctx->dist_counts.p, out_cap, nullptr);
+            else sk_bucket_kernel<0, false><<<g3, SK_ROLL_THREADS, 0, ctx->stream>>>(p, (u64 *)ctx->dist_keys.p, (u32 *)ctx->dist_counts.p, out_cap, nullptr);
+        }
+        HIPCHK(hipGetLastError());
+        u64 sc[10];
+        HIPCHK(hipMemcpyAsync(sc, ctx->d_scalars.p, 80, hipMemcpyDeviceToHost, ctx->stream));
+        if ((rc = tm.stop()) != PB_OK) return rc;
+        if (sc[7] + sc[8]) {                                       // buckets that left the LDS path: every window of theirs through the global table
+            sk_flagged_kernel<<<dim3(grid_for(nb2, 1, 1024), 16), 256, 0, ctx->stream>>>(p);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(sc, ctx->d_scalars.p, 80, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+        }
+        if (sc[1] == 0) {
+            ctx->n_distinct = sc[4];
+            ctx->hist_done = sc[4];
+            ctx->h_hist_valid = false;
+            ctx->sk_flagged = sc[7];
+            ctx->sk_spilled = sc[8];
+            ctx->stage_ms["sk_bucket_bits"] = (float)B;
+            ctx->stage_ms["sk_flagged_buckets"] = (float)sc[7];
+            ctx->stage_ms["sk_spilled_records"] = (float)sc[8];
+            if (sc[7] + sc[8]) { if ((rc = table_to_arrays<1>(ctx, ctx->table_cap, true)) != PB_OK) return rc; }
+            ctx->count_path = 2;
+            if ((rc = finish_count(ctx, occ_hist, max_occ)) != PB_OK) return rc;
+            if (n_distinct) *n_distinct = ctx->n_distinct;
+            return PB_OK;
+        }
+        if (sc[8] > p.spill_cap) { ctx->err = "pb_sk_count_records: the spill list overflowed"; return PB_ERANGE; }
+        fcap <<= 2;
+    }
+    ctx->err = "pb_sk_count_records: fallback table overflow";
+    return PB_ENOMEM;
+}
+
+} // extern "C"
 
 extern "C" {
 
@@ -1046,6 +1247,7 @@ static int merge_records_lds_impl(pb_ctx *ctx, const void *dev_keys, const void 
     p.B = B;
     p.l1 = B / 2;
     p.l2 = B - p.l1;
+    p.nx = PB_XCD;
     const u64 nb1 = (1ull << p.l1) * PB_XCD, nb2 = 1ull << B;
     p.cap1 = n / nb1 * 3 / 2 + 4096;
     p.cap2 = (u32)(n / nb2 * 2 + 256);

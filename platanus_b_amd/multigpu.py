@@ -73,6 +73,66 @@ def exchange_records_split(dist, torch, keys, counts16, n_single, n_multi, W: in
     return rk, rcnt, recv
 
 
+def count_exchanging_records(g, dist, world: int, rank: int, k: int):
+    """The N > 1 counting step with the exchange BEFORE the counting (k <= 32, world a power of two): every rank cuts its reads into
+    16-byte run records grouped by owner rank (owner = top bits of the minimizer bucket), ONE all_to_all moves them, every rank counts
+    what it received.  No export and no owner-side merge: copies of a run from different ranks meet in the bucket kernel's record
+    table like copies from different reads.  Afterwards g holds this rank's share of the global table (a partition by bucket, not by
+    the reference's stripes: any partition of the keys will do for retain + gather) and g.occ_hist / g.max_occ / g.n_distinct describe
+    the GLOBAL distribution."""
+    import torch
+    from .binding import PB_OCC_BINS
+    lib, h = g.lib, g.h
+    gloo = dist.get_backend() == "gloo"
+    dev = torch.device("cuda", torch.cuda.current_device())
+    cdev = torch.device("cpu") if gloo else dev
+    n_reads, n_bases = g.reads_info()
+    # every rank receives about what it holds: the bucket bits of a single GPU with the largest rank's windows
+    w = torch.tensor([max(n_bases - (k - 1) * n_reads, 1)], dtype=torch.int64, device=cdev)
+    dist.all_reduce(w, op=dist.ReduceOp.MAX)
+    if world & (world - 1):
+        raise ValueError("count_exchanging_records needs a power-of-two number of ranks")
+    n_owners = max(world, 2)                            # (one rank: two owner groups, both its own -- the single-rank RCCL test)
+    local_bits = min(int(lib.pb_sk_bucket_bits(int(w.item()))), 20 - (n_owners.bit_length() - 1))
+    counts = (C.c_uint64 * n_owners)()
+    nw = C.c_uint64()
+    g._chk(lib.pb_sk_owner_records(h, k, n_owners, local_bits, counts, C.byref(nw)))
+    send = [int(x) for x in counts] if world > 1 else [sum(int(x) for x in counts)]
+    sbuf = torch.empty(max(sum(send), 1) * 16, dtype=torch.uint8, device=dev)
+    g._chk(lib.pb_sk_owner_records_copy(h, C.c_void_p(sbuf.data_ptr())))
+    sc = torch.tensor(send, dtype=torch.int64, device=cdev)
+    rc = torch.empty(world, dtype=torch.int64, device=cdev)
+    dist.all_to_all_single(rc, sc)
+    recv = [int(x) for x in rc.tolist()]
+    if gloo:                                            # gloo has no all_to_all on device tensors: staged through the host (tests)
+        rb = torch.empty(max(sum(recv), 1) * 16, dtype=torch.uint8)
+        dist.all_to_all_single(rb[:sum(recv) * 16], sbuf[:sum(send) * 16].cpu(), [r * 16 for r in recv], [s * 16 for s in send])
+        rbuf = rb.to(dev)
+    else:
+        rbuf = torch.empty(max(sum(recv), 1) * 16, dtype=torch.uint8, device=dev)
+        dist.all_to_all_single(rbuf[:sum(recv) * 16], sbuf[:sum(send) * 16], [r * 16 for r in recv], [s * 16 for s in send])
+    torch.cuda.synchronize()                 # the library runs on its own stream
+    hist = np.zeros(PB_OCC_BINS, dtype=np.uint64)
+    mx, nd = C.c_uint64(), C.c_uint64()
+    g._chk(lib.pb_sk_count_records(h, k, C.c_void_p(rbuf.data_ptr()), sum(recv), local_bits, hist.ctypes.data, C.byref(mx), C.byref(nd)))
+    both = np.empty(PB_OCC_BINS + 2, dtype=np.int64)
+    both[:PB_OCC_BINS] = hist.astype(np.int64)
+    both[PB_OCC_BINS] = nd.value
+    both[PB_OCC_BINS + 1] = nw.value
+    th = torch.from_numpy(both).to(cdev)
+    dist.all_reduce(th)
+    tot = th.cpu().numpy()
+    g.k = k
+    g.occ_hist = tot[:PB_OCC_BINS].astype(np.uint64)
+    nz = np.nonzero(g.occ_hist[1:65535])[0]
+    g.max_occ = int(nz[-1]) + 1 if nz.size else 0
+    g.n_distinct_local = nd.value
+    g.n_distinct = int(tot[PB_OCC_BINS])
+    g.n_instances = int(tot[PB_OCC_BINS + 1])
+    g.records_sent, g.records_received = sum(send), sum(recv)
+    return g.occ_hist
+
+
 def gather_retained(dist, torch, keys: np.ndarray, counts: np.ndarray, W: int):
     """All-gather of the owners' retained (key,count) shards: keys uint64 [n, W] (word 0 least significant),
     counts uint16 [n] of THIS rank's shard -> (keys, counts) of the union on every rank, ascending by the 2k-bit key value, i.e. the

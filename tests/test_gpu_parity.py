@@ -413,6 +413,16 @@ def test_exchange_and_merge_over_rccl_single_rank(gpu, oracle_built):
             g.retain(2)
             gk, gc = g.fetch_retained()
             assert np.array_equal(gk, ok) and np.array_equal(gc, ocn)
+            if k <= 32:                                   # the other design: run records through the all_to_all, counted on arrival
+                from platanus_b_amd.multigpu import count_exchanging_records
+                g2 = gpu(0)
+                g2.reads_append_matrix(codes)
+                ghist2 = count_exchanging_records(g2, dist, 1, 0, k)
+                assert np.array_equal(ghist2, ohist) and g2.max_occ == omax and g2.n_distinct == int(ohist.sum())
+                assert g2.records_received == g2.records_sent > 0
+                g2.retain(2)
+                gk2, gc2 = g2.fetch_retained()
+                assert np.array_equal(gk2, ok) and np.array_equal(gc2, ocn)
     finally:
         dist.destroy_process_group()
 
@@ -579,11 +589,12 @@ def test_merge_records_through_lds_tables(gpu, oracle_built, monkeypatch):
         assert np.array_equal(gk.reshape(-1), ok.reshape(-1)) and np.array_equal(gc, expect), table_path
 
 
-@pytest.mark.parametrize("world,port", [(2, 29551), (4, 29552)])
-def test_two_ranks_share_one_gpu(world, port, oracle_built, tmp_path):
-    """The N > 1 step with real kernels: two (four) processes on GPU 0 (gloo collectives staged through the host), each counting half
-    of the read pairs with the super-k-mer pass, exporting by owner, merging what it owns through the LDS-table merge.  The
-    all-reduced histogram and the union of the two owner shards must equal the single-process oracle on all reads."""
+@pytest.mark.parametrize("world,port,design", [(2, 29551, "counts"), (4, 29552, "counts"), (2, 29553, "records"), (4, 29554, "records")])
+def test_two_ranks_share_one_gpu(world, port, design, oracle_built, tmp_path):
+    """The N > 1 step with real kernels: two (four) processes on GPU 0 (gloo collectives staged through the host), each holding half
+    (a quarter) of the read pairs.  Design "counts": super-k-mer count, export by owner, exchange of (key,count) records, LDS-table
+    merge.  Design "records": run records by owner, exchange of the records, then the counting (no export, no merge).  The all-reduced
+    histogram and the union of the ranks' shards must equal the single-process oracle on all reads."""
     import json
     import subprocess
     import sys
@@ -593,7 +604,7 @@ def test_two_ranks_share_one_gpu(world, port, oracle_built, tmp_path):
     out = tmp_path / "res.json"
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(ROOT, "tests", "_gpu2_worker.py"), str(k), str(genome), str(cov), str(seed), str(out)]
+           os.path.join(ROOT, "tests", "_gpu2_worker.py"), str(k), str(genome), str(cov), str(seed), str(out), design]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
     res = json.load(open(out))
