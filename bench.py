@@ -169,6 +169,7 @@ def main():
     ap.add_argument("--exchange", choices=["records", "counts"], default="records",
                     help="N > 1 step: 'records' = run records by owner, ONE all_to_all, counted on arrival (power-of-two N); 'counts' = count, "
                          "export (key,count) by owner, all_to_all, owner-side merge")
+    ap.add_argument("--exchange-with-one-rank", action="store_true", help=argparse.SUPPRESS)      # tests: the N > 1 step on a world of one (RCCL to itself)
     ap.add_argument("--shard-shapes-only", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
     if a.shard_shapes_only:
@@ -186,14 +187,20 @@ def main():
         sys.exit("bench.py needs a GPU (no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or a.exchange_with_one_rank:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from platanus_b_amd import synth
     from platanus_b_amd.binding import GpuCounter
     from platanus_b_amd.multigpu import count_exchanging_records, exchange_and_merge
-    by_records = world > 1 and a.exchange == "records" and world & (world - 1) == 0
+    exchanging = world > 1 or a.exchange_with_one_rank
+    by_records = exchanging and a.exchange == "records" and world & (world - 1) == 0
 
     # this rank's range of read pairs: rank r of a (COVERAGE*world)x set holds pairs [r*P, (r+1)*P)
     pairs_per_rank = int(a.genome * COVERAGE) // (2 * READ_LEN)
@@ -213,7 +220,7 @@ def main():
             count_exchanging_records(g, dist, world, rank, K)
         else:
             g.make_kmer_read_distribution(K)
-            if world > 1:
+            if exchanging:
                 exchange_and_merge(g, dist, world, rank)
 
     for _ in range(a.warmup):

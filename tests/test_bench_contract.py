@@ -33,3 +33,16 @@ def test_bench_json_line():
     assert abs(d["value"] - inst / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
     assert r["kernel_ms"] <= d["ms_per_step"] and abs(r["achieved"] - inst * 12.25 / (r["kernel_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-6
     assert r["kernels_ms"]["part1"] > 0                   # the pass bench.py measures is the super-k-mer pass
+
+
+@pytest.mark.parametrize("design", ["records", "counts"])
+def test_bench_n_rank_step_on_a_world_of_one(design):
+    """The N > 1 step of bench.py (both designs) with torch.distributed over RCCL on a world of one: the same code the driver's
+    `--gpus N` runs execute, minus the other ranks."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--genome", "300000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                        "--exchange-with-one-rank", "--exchange", design], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][-1])
+    assert d["n_gpus"] == 1 and d["config"]["torch_distributed"] == {"backend": "nccl", "world_size": 1}
+    assert d["value"] > 0 and d["roofline"]["kernel_ms"] > 0
+    assert d["config"]["distinct_kmers"] > 200_000
