@@ -152,6 +152,9 @@ int pb_dist_info(const pb_ctx *ctx, int *rank, int *world, int *rccl);
 int pb_dist_barrier(pb_ctx *ctx);
 int pb_dist_allreduce_u64(pb_ctx *ctx, uint64_t *buf, uint64_t n);
 int pb_dist_merge_counts(pb_ctx *ctx, uint64_t *occ_hist, uint64_t *max_occ, uint64_t *n_distinct);
+/* pb_count over all ranks' reads in one call: for k <= 32 and a power-of-two number of ranks the run records are exchanged BEFORE they are
+ * counted (pb_sk_owner_records / pb_sk_count_records: no export, no merge); otherwise pb_count + pb_dist_merge_counts */
+int pb_dist_count(pb_ctx *ctx, unsigned k, uint64_t *occ_hist, uint64_t *max_occ, uint64_t *n_instances, uint64_t *n_distinct);
 int pb_dist_count_considering_contigs(pb_ctx *ctx, unsigned k, uint64_t *occ_hist, uint64_t *max_occ, uint64_t *n_distinct);
 int pb_dist_gather_retained(pb_ctx *ctx, uint64_t *n_total);
 

@@ -133,6 +133,7 @@ struct pb_ctx {
     int sk_force_bits = 0;          // bucket bits of the super-k-mer pass (0 = by input size)
     int sk_force_l1 = 0;            // ... of which level 1 (0 = half)
     int opt_merge_table = 0, opt_merge_16b = 0, opt_chain_rank_full = 0, opt_grid_cap = 0, opt_verbose = 0;
+    int opt_dist_design = 0;        // pb_dist_count: 0 = records before counting where it applies, 1 = always count + exchange (key,count) + merge
 
     // owner exchange (X1)
     DevBuf exp_keys, exp_counts, merge_table;
@@ -323,6 +324,7 @@ int pb_set_option(pb_ctx *ctx, const char *name, long value)
     else if (n == "merge_16b" && (value == 0 || value == 1)) ctx->opt_merge_16b = (int)value;
     else if (n == "chain_rank_full" && (value == 0 || value == 1)) ctx->opt_chain_rank_full = (int)value;
     else if (n == "verbose" && (value == 0 || value == 1)) ctx->opt_verbose = (int)value;
+    else if (n == "dist_design" && (value == 0 || value == 1)) ctx->opt_dist_design = (int)value;
     else if (n == "grid_cap" && value >= 0 && value <= (1 << 20)) ctx->opt_grid_cap = (int)value;
     else { ctx->err = "pb_set_option: unknown option or value out of range: " + n; return PB_EINVAL; }
     return PB_OK;

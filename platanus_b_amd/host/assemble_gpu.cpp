@@ -81,6 +81,7 @@ struct Driver {
         if (!creator.joinable()) return;
         creator.join();
         if (create_rc != PB_OK) throw GpuError(create_rc, std::string("libpbgpu: ") + pb_last_error(nullptr));
+        for (const auto &nv : opt.gpu_options) chk(pb_set_option(ctx, nv.first.c_str(), nv.second));
         if (dist()) chk(pb_dist_attach(ctx, opt.shared, opt.rank, opt.world, opt.rccl ? 1 : 0));
         hook(std::get<0>(graphs)); hook(std::get<1>(graphs)); hook(std::get<2>(graphs)); hook(std::get<3>(graphs)); hook(std::get<4>(graphs));
     }
@@ -197,12 +198,16 @@ struct Driver {
         cutoff.clear();
         u64 n_inst = 0, n_distinct = 0;
         {
-            Tick t("count k0 (device)");
-            chk(pb_count(ctx, k[0], occ_hist.data(), &max_occ, &n_inst, &n_distinct));
+            Tick t(dist() ? "count k0 (device, all ranks)" : "count k0 (device)");
+            // N ranks: every rank's reads, one global table spread over the ranks (run records exchanged by bucket owner and counted on
+            // arrival; or count + owner exchange of (key,count) records + merge)
+            if (dist()) chk(pb_dist_count(ctx, k[0], occ_hist.data(), &max_occ, &n_inst, &n_distinct));
+            else chk(pb_count(ctx, k[0], occ_hist.data(), &max_occ, &n_inst, &n_distinct));
         }
-        if (dist()) {
-            Tick t("owner exchange + merge of the occurrence tables (ranks)");
-            chk(pb_dist_merge_counts(ctx, occ_hist.data(), &max_occ, &n_distinct));
+        if (dist()) {                                  // (PB_TIMING: which of the two designs the ranks agreed on)
+            float by_records = 0.f;
+            (void)pb_last_kernel_ms(ctx, "dist_by_records", &by_records);
+            g_clock.add(by_records > 0.f ? "  (k0: run records exchanged before the counting)" : "  (k0: counted per rank, (key,count) tables exchanged and merged)", 0.0);
         }
         const u64 llm = left_local_minimal_value(occ_hist, max_occ, 1);
         if (!opt.repeat) cutoff.push_back(opt.n_cutoff != 0 ? opt.n_cutoff : std::max<u64>(llm / 2, 2ull));

@@ -1,6 +1,7 @@
 // Options of `platanus_b assemble` (defaults: assemble.cpp:55-70) + the device to run on.
 #pragma once
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace pbh {
@@ -26,6 +27,7 @@ struct GpuAssembleOptions {
     int rank = 0, world = 1;
     void *shared = nullptr;              // pb_dist_shared_create's block, made before the ranks were forked
     bool rccl = true;                    // record exchange over RCCL (one GPU per rank); false: through shared host memory
+    std::vector<std::pair<std::string, long long>> gpu_options;   // -gpu_opt NAME=INT: pb_set_option after pb_create
 };
 
 int run_assemble_gpu(const GpuAssembleOptions &opt);

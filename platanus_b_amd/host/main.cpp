@@ -41,6 +41,7 @@ static void usage()
               << "                           merged by key owner over RCCL before every graph stage; same output files\n"
               << "    -share_gpu           : with -gpus N: all ranks on device -gpu, records exchanged through shared host memory (tests)\n"
               << "    -comm STR            : with -gpus N: rccl (default) or host (shared host memory instead of RCCL)\n"
+              << "    -gpu_opt NAME=INT    : pb_set_option of libpbgpu (selects device code paths; results do not change)\n"
               << "    (-repeat is refused: the reference itself crashes in that mode, DESIGN.md section 1)\n"
               << "\n\nOutputs:\n    PREFIX_contig.fa\n    PREFIX_kmerFrq.tsv\n\nNote, PREFIX is specified by -o\n" << std::endl;
 }
@@ -169,6 +170,12 @@ int main(int argc, char **argv)
         else if (a == "-gpus") n_ranks = atoi(val().c_str());
         else if (a == "-share_gpu") share_gpu = true;
         else if (a == "-comm") comm = val();
+        else if (a == "-gpu_opt") {              // NAME=VALUE for pb_set_option (which kernels run, never what they return)
+            const std::string nv = val();
+            const size_t eq = nv.find('=');
+            if (eq == std::string::npos) { usage(); return 1; }
+            o.gpu_options.emplace_back(nv.substr(0, eq), atoll(nv.c_str() + eq + 1));
+        }
         else if (a == "-kmer_occ_only") o.kmer_occ_only = true;
         else if (a == "-repeat") o.repeat = true;
         else if (a == "-f") { o.files.clear(); while (i + 1 < argc && argv[i + 1][0] != '-') o.files.push_back(argv[++i]); }   // (a repeated -f replaces the list, baseCommand.cpp:70)

@@ -83,6 +83,24 @@ def test_cli_n_ranks_write_the_reference_files(world, name, run, manifest, tmp_p
             assert filecmp.cmp(tmp_path / fn, gold, shallow=False), fn
 
 
+@pytest.mark.parametrize("world,name,run", [(2, "c2", "multik_n2"), (4, "c1", "multik"), (2, "het", "u1")])
+def test_cli_n_ranks_exchanging_run_records(world, name, run, manifest, tmp_path):
+    """The same with the k0 counting done the other way round (pb_dist_count: run records grouped by the owner of their minimizer
+    bucket, exchanged, counted on arrival) -- forced here with -gpu_opt count_path=2 because these inputs are below the size at which
+    it is the default; the stage list (PB_TIMING) says which design the ranks agreed on."""
+    case = manifest[name]
+    info = case["runs"][run]
+    from platanus_b_amd import synth
+    synth.write_pair_files(str(tmp_path / "in"), case["genome"], case["cov"], case["seed"], err=case["err"], n_rate=case["n_rate"], het=case.get("het", 0.0))
+    p = subprocess.run([BIN, "assemble", *info["args"], "-gpus", str(world), "-share_gpu", "-gpu_opt", "count_path=2", "-o", "out", "-f", "in_1.fq", "in_2.fq"],
+                       cwd=tmp_path, capture_output=True, text=True, timeout=900, env=dict(os.environ, PB_TIMING="1"))
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert "run records exchanged before the counting" in p.stderr, p.stderr[-3000:]
+    for fn, meta in info["files"].items():
+        assert (tmp_path / fn).exists(), fn
+        assert _md5(tmp_path / fn) == meta["md5"], fn
+
+
 def test_cli_n_ranks_refuses_kmer_occ_only(tmp_path):
     from platanus_b_amd import synth
     synth.write_pair_files(str(tmp_path / "in"), 5000, 20, 3)
