@@ -622,7 +622,7 @@ static int count_superk(pb_ctx *ctx, unsigned k, bool *done, bool want_pos = fal
         p.cap2 = (u32)std::min<double>(est_rec / (double)nb2 * 3.0 + 256.0, 1e9);   // minimizer sites are few per bucket: sizes vary a lot
         if ((rc = ensure(ctx, ctx->part_bucket1, nb1 * p.cap1 * SkStore16::BYTES)) != PB_OK) return rc;
         if ((rc = ensure(ctx, ctx->part_bucket2, (nb2 * (u64)p.cap2 + 1024) * SkStore16::BYTES)) != PB_OK) return rc;
-        if ((rc = ensure(ctx, ctx->part_meta, (nb1 + 2 * nb2) * 4)) != PB_OK) return rc;
+        if ((rc = ensure(ctx, ctx->part_meta, (nb1 * SK_CUR1_STRIDE + 2 * nb2) * 4)) != PB_OK) return rc;
         p.spill_cap = std::max<u64>((u64)(est_rec / 16), 1ull << 16);
         if ((rc = ensure(ctx, ctx->part_spill, p.spill_cap * SkStore16::BYTES)) != PB_OK) return rc;
         p.pos1 = p.pos2 = nullptr;
@@ -636,7 +636,7 @@ static int count_superk(pb_ctx *ctx, unsigned k, bool *done, bool want_pos = fal
         p.bucket1 = ctx->part_bucket1.p;
         p.bucket2 = ctx->part_bucket2.p;
         p.cursor1 = (u32 *)ctx->part_meta.p;
-        p.cursor2 = p.cursor1 + nb1;
+        p.cursor2 = p.cursor1 + nb1 * SK_CUR1_STRIDE;
         p.flag2 = p.cursor2 + nb2;
         // the distinct arrays are written in place: room for every bucket's table full, plus the fallback table's records
         const u64 out_cap = std::min<u64>(std::max<u64>(ctx->stream_len, 1), nb2 * (u64)SK_SLOT_LIMIT);
@@ -651,7 +651,7 @@ static int count_superk(pb_ctx *ctx, unsigned k, bool *done, bool want_pos = fal
         p.hist = (u64 *)ctx->d_hist.p;
         HIPCHK(hipMemsetAsync(ctx->d_hist.p, 0, 65536 * 8, ctx->stream));
         HIPCHK(hipMemsetAsync(ctx->d_scalars.p, 0, 16 * 8, ctx->stream));
-        HIPCHK(hipMemsetAsync(ctx->part_meta.p, 0, (nb1 + 2 * nb2) * 4, ctx->stream));
+        HIPCHK(hipMemsetAsync(ctx->part_meta.p, 0, (nb1 * SK_CUR1_STRIDE + 2 * nb2) * 4, ctx->stream));
         LazyTimer ti(ctx, "table_init", 3);
         table_init_kernel<1><<<grid_for(fcap * 2, 256, 256 * 32), 256, 0, ctx->stream>>>(p.fallback.slots, fcap);
         ti.stop();
@@ -698,12 +698,14 @@ static int count_superk(pb_ctx *ctx, unsigned k, bool *done, bool want_pos = fal
             (void)hipMemcpyFromSymbol(&v[2], HIP_SYMBOL(sk_dbg_parked), 8); (void)hipMemcpyFromSymbol(&v[3], HIP_SYMBOL(sk_dbg_steps), 8);
             (void)hipMemcpyFromSymbol(&v[4], HIP_SYMBOL(sk_dbg_inserts), 8);
             {
-                unsigned long long c1[12], t1 = 0;
-                (void)hipMemcpyFromSymbol(c1, HIP_SYMBOL(sk1_dbg_cyc), 96);
-                for (int i = 0; i < 12; ++i) t1 += c1[i];
-                static const char *n1[12] = {"stage the tile", "barrier 1", "hashes + store", "barrier 2", "a8 (neighbours, doubling, store)", "barrier 3", "window minima (3 x 17 reads)",
-                                             "barrier 4", "run starts + digit histogram", "rank scan (2 barriers)", "digit scan + record build", "barrier + copy-out"};
-                for (int i = 0; i < 12; ++i) fprintf(stderr, "[pbgpu]   part1 wave cycles %-34s %5.1f %%\n", n1[i], 100.0 * (double)c1[i] / (double)t1);
+                unsigned long long c1[16], t1 = 0;
+                (void)hipMemcpyFromSymbol(c1, HIP_SYMBOL(sk1_dbg_cyc), 128);
+                for (int i = 0; i < 16; ++i) t1 += c1[i];
+                static const char *n1[16] = {"tile end: stage, clear, barrier", "barrier before the records leave", "hashes + store", "barrier 2", "a8 (neighbours, doubling, store)", "barrier 3",
+                                             "window minima (3 x 17 reads)", "barrier 4", "run starts", "rank scan (2 barriers)", "reserve + first record build", "records leave, further builds, barrier",
+                                             "list of starts", "barrier 5", "digit histogram", "barrier 6"};
+                static const int order[16] = {2, 3, 4, 5, 6, 7, 8, 9, 12, 13, 14, 15, 10, 1, 11, 0};
+                for (int q = 0; q < 16; ++q) { const int i = order[q]; fprintf(stderr, "[pbgpu]   part1 wave cycles %-40s %5.1f %%\n", n1[i], 100.0 * (double)c1[i] / (double)t1); }
             }
             unsigned long long cyc[12];
             (void)hipMemcpyFromSymbol(cyc, HIP_SYMBOL(sk_dbg_cyc), 96);
@@ -850,17 +852,17 @@ int pb_sk_owner_records(pb_ctx *ctx, unsigned k, unsigned n_owners, unsigned loc
     p.cap1 = (u64)(est_rec / (double)n_owners * 1.5) + 65536;
     p.cap2 = 0;
     if ((rc = ensure(ctx, ctx->part_bucket1, (u64)n_owners * p.cap1 * SkStore16::BYTES)) != PB_OK) return rc;
-    if ((rc = ensure(ctx, ctx->part_meta, ((u64)n_owners + 2ull * (1ull << p.B)) * 4)) != PB_OK) return rc;
+    if ((rc = ensure(ctx, ctx->part_meta, ((u64)n_owners * SK_CUR1_STRIDE + 2ull * (1ull << p.B)) * 4)) != PB_OK) return rc;
     p.spill_cap = 1ull << 16;
     if ((rc = ensure(ctx, ctx->part_spill, p.spill_cap * SkStore16::BYTES)) != PB_OK) return rc;
     p.spill = ctx->part_spill.p;
     p.bucket1 = ctx->part_bucket1.p;
     p.cursor1 = (u32 *)ctx->part_meta.p;
-    p.cursor2 = p.cursor1 + n_owners;
+    p.cursor2 = p.cursor1 + (u64)n_owners * SK_CUR1_STRIDE;
     p.flag2 = p.cursor2 + (1ull << p.B);                       // (only written when a record does not fit its owner's region)
     p.scalars = (u64 *)ctx->d_scalars.p;
     HIPCHK(hipMemsetAsync(ctx->d_scalars.p, 0, 16 * 8, ctx->stream));
-    HIPCHK(hipMemsetAsync(ctx->part_meta.p, 0, ((u64)n_owners + 2ull * (1ull << p.B)) * 4, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->part_meta.p, 0, ((u64)n_owners * SK_CUR1_STRIDE + 2ull * (1ull << p.B)) * 4, ctx->stream));
     {
         StageTimer t1(ctx, "part1");
         const u64 n_tiles = (ctx->stream_len + SK1_OWN - 1) / SK1_OWN;
@@ -875,10 +877,11 @@ int pb_sk_owner_records(pb_ctx *ctx, unsigned k, unsigned n_owners, unsigned loc
         if ((rc = t1.stop()) != PB_OK) return rc;
     }
     u64 sc[10];
-    std::vector<u32> cur(n_owners);
+    std::vector<u32> cur_strided((u64)n_owners * SK_CUR1_STRIDE), cur(n_owners);
     HIPCHK(hipMemcpyAsync(sc, ctx->d_scalars.p, 80, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(cur.data(), p.cursor1, n_owners * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(cur_strided.data(), p.cursor1, cur_strided.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (unsigned o = 0; o < n_owners; ++o) cur[o] = cur_strided[(u64)o * SK_CUR1_STRIDE];
     if (sc[8] || sc[1]) { ctx->err = "pb_sk_owner_records: an owner's region overflowed (a few minimizers carry most of the input)"; return PB_ERANGE; }
     for (unsigned o = 0; o < n_owners; ++o) { counts[o] = cur[o]; ctx->exp_cur[o] = cur[o]; }
     ctx->exp_parts = n_owners;
@@ -935,14 +938,14 @@ int pb_sk_count_records(pb_ctx *ctx, unsigned k, const void *dev_records, uint64
     // (it is not: callers pass their own buffer), so a second buffer is used for them
     if ((rc = ensure(ctx, ctx->scratch[4], nb1 * p.cap1 * SkStore16::BYTES)) != PB_OK) return rc;
     if ((rc = ensure(ctx, ctx->part_bucket2, (nb2 * (u64)p.cap2 + 1024) * SkStore16::BYTES)) != PB_OK) return rc;
-    if ((rc = ensure(ctx, ctx->part_meta, (nb1 + 2 * nb2) * 4)) != PB_OK) return rc;
+    if ((rc = ensure(ctx, ctx->part_meta, (nb1 * SK_CUR1_STRIDE + 2 * nb2) * 4)) != PB_OK) return rc;
     p.spill_cap = std::max<u64>((u64)(est_rec / 16), 1ull << 16);
     if ((rc = ensure(ctx, ctx->part_spill, p.spill_cap * SkStore16::BYTES)) != PB_OK) return rc;
     p.spill = ctx->part_spill.p;
     p.bucket1 = ctx->scratch[4].p;
     p.bucket2 = ctx->part_bucket2.p;
     p.cursor1 = (u32 *)ctx->part_meta.p;
-    p.cursor2 = p.cursor1 + nb1;
+    p.cursor2 = p.cursor1 + nb1 * SK_CUR1_STRIDE;
     p.flag2 = p.cursor2 + nb2;
     const u64 out_cap = std::min<u64>(std::max<u64>(n_records * SK_RUN_MAXLEN, 1), nb2 * (u64)SK_SLOT_LIMIT);
     u64 fcap = 1ull << 20;
@@ -957,7 +960,7 @@ int pb_sk_count_records(pb_ctx *ctx, unsigned k, const void *dev_records, uint64
         p.hist = (u64 *)ctx->d_hist.p;
         HIPCHK(hipMemsetAsync(ctx->d_hist.p, 0, 65536 * 8, ctx->stream));
         HIPCHK(hipMemsetAsync(ctx->d_scalars.p, 0, 16 * 8, ctx->stream));
-        HIPCHK(hipMemsetAsync(ctx->part_meta.p, 0, (nb1 + 2 * nb2) * 4, ctx->stream));
+        HIPCHK(hipMemsetAsync(ctx->part_meta.p, 0, (nb1 * SK_CUR1_STRIDE + 2 * nb2) * 4, ctx->stream));
         table_init_kernel<1><<<grid_for(fcap * 2, 256, 256 * 32), 256, 0, ctx->stream>>>(p.fallback.slots, fcap);
         StageTimer tm(ctx, "count_records");
         if (n_records) {
@@ -1255,14 +1258,14 @@ static int merge_records_lds_impl(pb_ctx *ctx, const void *dev_keys, const void 
     p.cap2 = (u32)(n / nb2 * 2 + 256);
     if ((rc = ensure(ctx, ctx->part_bucket1, nb1 * p.cap1 * G::BYTES)) != PB_OK) return rc;
     if ((rc = ensure(ctx, ctx->part_bucket2, nb2 * (u64)p.cap2 * G::BYTES)) != PB_OK) return rc;
-    if ((rc = ensure(ctx, ctx->part_meta, (nb1 + 2 * nb2) * 4)) != PB_OK) return rc;
+    if ((rc = ensure(ctx, ctx->part_meta, (nb1 * SK_CUR1_STRIDE + 2 * nb2) * 4)) != PB_OK) return rc;
     p.spill_cap = 1ull << 16;
     if ((rc = ensure(ctx, ctx->part_spill, p.spill_cap * sizeof(SkRec))) != PB_OK) return rc;
     p.spill = ctx->part_spill.p;
     p.bucket1 = ctx->part_bucket1.p;
     p.bucket2 = ctx->part_bucket2.p;
     p.cursor1 = (u32 *)ctx->part_meta.p;
-    p.cursor2 = p.cursor1 + nb1;
+    p.cursor2 = p.cursor1 + nb1 * SK_CUR1_STRIDE;
     p.flag2 = p.cursor2 + nb2;
     p.fallback = TableView<1>{nullptr, 0};
     if ((rc = ensure(ctx, ctx->d_hist, 65536 * 8)) != PB_OK) return rc;
@@ -1272,7 +1275,7 @@ static int merge_records_lds_impl(pb_ctx *ctx, const void *dev_keys, const void 
     if ((rc = ensure(ctx, ctx->dist_keys, n * 8)) != PB_OK) return rc;
     if ((rc = ensure(ctx, ctx->dist_counts, n * 4)) != PB_OK) return rc;
     HIPCHK(hipMemsetAsync(ctx->d_scalars.p, 0, 16 * 8, ctx->stream));
-    HIPCHK(hipMemsetAsync(ctx->part_meta.p, 0, (nb1 + 2 * nb2) * 4, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->part_meta.p, 0, (nb1 * SK_CUR1_STRIDE + 2 * nb2) * 4, ctx->stream));
     StageTimer tm(ctx, "merge");
     mg_part1_kernel<G><<<grid_for((n + SK2_RCAP - 1) / SK2_RCAP, 1, 256 * 8), SK_THREADS, 0, ctx->stream>>>((const u64 *)dev_keys, (const u32 *)dev_counts, n, p);
     const u64 exp_tiles = n / nb1 / SK2_RCAP + 1;
