@@ -126,6 +126,7 @@ struct pb_ctx {
     unsigned exp2_parts = 0;
     u64 sk_records = 0;            // super-k-mer records of the last counting pass (0 = other path)
     u64 sk_flagged = 0, sk_spilled = 0, sk_extra_for = 0;
+    u64 sk_fcap = 0, sk_fcap_for = 0;   // capacity of the fallback table that an earlier pass over the same stream needed
     u64 hist_done = 0;              // leading records of the distinct arrays already tallied into d_hist
     unsigned sk_bits = 0, sk_extra_bits = 0;       // bucket bits used; extra bits that an earlier pass over the same stream needed
     // pb_set_option: choices between equivalent implementations (tests and A/B runs; no option changes a result)
@@ -318,7 +319,7 @@ int pb_set_option(pb_ctx *ctx, const char *name, long value)
     if (!ctx || !name) return PB_EINVAL;
     const std::string n(name);
     if (n == "count_path" && value >= 0 && value <= 2) ctx->opt_count_path = (int)value;
-    else if (n == "sk_bucket_bits" && (value == 0 || (value >= 2 && value <= 18))) ctx->sk_force_bits = (int)value;
+    else if (n == "sk_bucket_bits" && (value == 0 || (value >= 2 && value <= SK_MAX_B))) ctx->sk_force_bits = (int)value;
     else if (n == "sk_l1_bits" && value >= 0 && value <= 9) ctx->sk_force_l1 = (int)value;
     else if (n == "merge_table" && (value == 0 || value == 1)) ctx->opt_merge_table = (int)value;
     else if (n == "merge_16b" && (value == 0 || value == 1)) ctx->opt_merge_16b = (int)value;
@@ -603,14 +604,15 @@ static int count_superk(pb_ctx *ctx, unsigned k, bool *done, bool want_pos = fal
     // SK_SLOTS-slot LDS table.  Low-coverage data has more distinct keys per window; the pass is then repeated with 4x the
     // buckets (see below) and the context remembers what worked.
     unsigned B = 8;
-    while (((u64)(SK_SLOTS * 3) << B) < windows && B < 18) ++B;
-    if (ctx->sk_extra_bits && ctx->sk_extra_for == windows) B = std::min(18u, B + ctx->sk_extra_bits);
+    while (((u64)(SK_SLOTS * 3) << B) < windows && B < SK_MAX_B) ++B;
+    if (ctx->sk_extra_bits && ctx->sk_extra_for == windows) B = std::min((unsigned)SK_MAX_B, B + ctx->sk_extra_bits);
     bool forced_b = false;
-    if (ctx->sk_force_bits >= 2 && ctx->sk_force_bits <= 18) { B = (unsigned)ctx->sk_force_bits; forced_b = true; }
-    u64 fcap = 1ull << 20;
+    if (ctx->sk_force_bits >= 2 && ctx->sk_force_bits <= SK_MAX_B) { B = (unsigned)ctx->sk_force_bits; forced_b = true; }
+    u64 fcap = ctx->sk_fcap && ctx->sk_fcap_for == windows ? ctx->sk_fcap : 1ull << 20;
+    double room2 = ctx->sk_fcap && ctx->sk_fcap_for == windows ? 6.0 : 3.0;      // final-bucket capacity over the mean
     for (int attempt = 0; attempt < 12; ++attempt) {
         p.B = B;
-        p.l1 = B / 2;
+        p.l1 = std::max(B / 2, B > 9 ? B - 9 : 0u);                  // (a level has at most 2^9 digits in sk_part2; sk_part1 takes up to 2^11)
         if (ctx->sk_force_l1 >= 1 && ctx->sk_force_l1 < (int)B && (int)B - ctx->sk_force_l1 <= 9) p.l1 = (unsigned)ctx->sk_force_l1;
         p.l2 = B - p.l1;
         // expected windows per record: a run ends when a smaller m-mer enters the window or the minimizer leaves it -- (w + 1) / 2
@@ -619,7 +621,7 @@ static int count_superk(pb_ctx *ctx, unsigned k, bool *done, bool want_pos = fal
         p.nx = PB_XCD;
         const u64 nb1 = (1ull << p.l1) * PB_XCD, nb2 = 1ull << B;
         p.cap1 = (u64)(est_rec / (double)nb1 * 1.5) + 4096;
-        p.cap2 = (u32)std::min<double>(est_rec / (double)nb2 * 3.0 + 256.0, 1e9);   // minimizer sites are few per bucket: sizes vary a lot
+        p.cap2 = (u32)std::min<double>(est_rec / (double)nb2 * room2 + 256.0, 1e9);   // minimizer sites are few per bucket: sizes vary a lot
         if ((rc = ensure(ctx, ctx->part_bucket1, nb1 * p.cap1 * SkStore16::BYTES)) != PB_OK) return rc;
         if ((rc = ensure(ctx, ctx->part_bucket2, (nb2 * (u64)p.cap2 + 1024) * SkStore16::BYTES)) != PB_OK) return rc;
         if ((rc = ensure(ctx, ctx->part_meta, (nb1 * SK_CUR1_STRIDE + 2 * nb2) * 4)) != PB_OK) return rc;
@@ -728,13 +730,13 @@ static int count_superk(pb_ctx *ctx, unsigned k, bool *done, bool want_pos = fal
         }
         // sc[7] buckets had more distinct keys than an LDS table holds.  Many of them: the input is not the high-coverage kind
         // the bucket count was chosen for -- repeat with 4x the buckets rather than push a large share through the global table.
-        if (!forced_b && sc[7] > nb2 / 64 && B < 18) {
-            B = std::min(18u, B + 2);
+        if (!forced_b && sc[7] > nb2 / 64 && B < SK_MAX_B) {
+            B = std::min((unsigned)SK_MAX_B, B + 2);
             ctx->sk_extra_bits += 2;
             ctx->sk_extra_for = windows;
             continue;
         }
-        if (!forced_b && sc[7] > nb2 / 4) return PB_OK;            // still mostly overflowing at 2^18 buckets: the direct path takes it
+        if (!forced_b && sc[7] > nb2 / 4) return PB_OK;            // still mostly overflowing at 2^20 buckets: the direct path takes it
         ctx->stage_ms["seg_compact"] = 0.f;
         const bool all_in_lds = sc[7] + sc[8] == 0;                // then h_hist already holds the whole histogram
         if (want_pos && !all_in_lds) return PB_OK;                 // records that left the LDS path carry no position: the caller takes the probing kernel
@@ -761,8 +763,11 @@ static int count_superk(pb_ctx *ctx, unsigned k, bool *done, bool want_pos = fal
             break;
         }
         if (sc[8] > p.spill_cap) return PB_OK;   // a few minimizers carry most of the input (tiny k, low-complexity reads): the direct path takes it
-        fcap <<= 2;                     // the fallback table overflowed: retry with a larger one
-        if (attempt == 11) { ctx->err = "fallback table overflow"; return PB_ENOMEM; }
+        if (sc[8]) room2 = 6.0;         // (records spilled: a small genome at high coverage has ~1 minimizer site per bucket, sizes are Poisson)
+        fcap <<= 4;                     // the fallback table overflowed: retry with a larger one (remembered for the next pass over this stream)
+        ctx->sk_fcap = fcap;
+        ctx->sk_fcap_for = windows;
+        if (attempt == 11 || fcap > (1ull << 36)) { ctx->err = "fallback table overflow"; return PB_ENOMEM; }
     }
     ctx->stage_ms["count"] = ctx->stage_ms["part1"] + ctx->stage_ms["part2"] + ctx->stage_ms["bucket"] + ctx->stage_ms["seg_compact"];
     ctx->stage_ms["compact"] = 0.f;
@@ -816,14 +821,14 @@ static int sort_retained(pb_ctx *ctx, u64 n)
 static unsigned sk_bits_for(u64 windows)
 {
     unsigned B = 8;
-    while (((u64)(SK_SLOTS * 3) << B) < windows && B < 18) ++B;
+    while (((u64)(SK_SLOTS * 3) << B) < windows && B < SK_MAX_B) ++B;
     return B;
 }
 
 extern "C" {
 
 // bucket bits the super-k-mer pass would use for `windows` k-mer instances on one GPU (all ranks must agree on local_bits below)
-unsigned pb_sk_bucket_bits(uint64_t windows) { return sk_bits_for(windows); }
+unsigned pb_sk_bucket_bits(uint64_t windows) { return std::min(sk_bits_for(windows), 18u); }
 
 // Stage 1: run records of this rank's reads, grouped by owner (n_owners a power of two >= 2; owner = top bits of the
 // (log2(n_owners) + local_bits)-bit bucket).  counts[o] = records for owner o (16 bytes each); *n_windows = windows they hold.
@@ -912,7 +917,7 @@ int pb_sk_owner_records_copy(pb_ctx *ctx, void *dev_records)
 int pb_sk_count_records(pb_ctx *ctx, unsigned k, const void *dev_records, uint64_t n_records, unsigned local_bits, uint64_t *occ_hist, uint64_t *max_occ,
                         uint64_t *n_distinct)
 {
-    if (!ctx || k < 1 || k > 32 || (n_records && !dev_records) || local_bits < 2 || local_bits > 18) return PB_EINVAL;
+    if (!ctx || k < 1 || k > 32 || (n_records && !dev_records) || local_bits < 2 || local_bits > 18) return PB_EINVAL;      // (both levels go through sk_part2: 9 + 9 bits)
     (void)hipSetDevice(ctx->dev);
     int rc;
     ctx->k = k;

@@ -511,10 +511,11 @@ def test_superkmer_count_path_matches_oracle(k, gpu, oracle_built, monkeypatch):
     _superk_case(gpu, oracle_built, np.concatenate([r1, r2]), k, must_take_path=k >= 9)
 
 
-@pytest.mark.parametrize("bits", [2, 9, 15, 18])
+@pytest.mark.parametrize("bits", [2, 9, 15, 18, 19, 20])
 def test_superkmer_other_bucket_counts(bits, gpu, oracle_built, monkeypatch):
-    """4 .. 2^18 minimizer buckets: 4 buckets overflow their LDS tables and go through the global table, 2^18 is what a
-    3 G-window shard would use (longest records shrink to 21 windows)."""
+    """4 .. 2^20 minimizer buckets: 4 buckets overflow their LDS tables and go through the global table, 2^18 is what a
+    3 G-window shard would use, 2^20 (level 1 with 2^11 digits per XCD: the reservation loop instead of one lane per digit, 24 KB of
+    digit arrays) what 13 G windows on one GPU would -- BASELINE configs[4] whole on one device."""
     from platanus_b_amd import synth
     monkeypatch.setitem(GpuCounter.default_options, "count_path", COUNT_PATH["superk"])
     monkeypatch.setitem(GpuCounter.default_options, "sk_bucket_bits", bits)
