@@ -75,6 +75,15 @@ def main():
             outs = {}
             ranks = int(rng.choice([1, 1, 2, 3]))
             gpu_extra = ["-gpus", str(ranks), "-share_gpu"] if ranks > 1 else []
+            # device code paths that these small inputs would not take by themselves (same results): the super-k-mer pass for k0 <= 32
+            # -- with N ranks that is the records-before-counting exchange --, odd bucket counts, the other N-rank design
+            path = int(rng.integers(0, 4))
+            if path == 1:
+                gpu_extra += ["-gpu_opt", "count_path=2"]
+            elif path == 2:
+                gpu_extra += ["-gpu_opt", "count_path=2", "-gpu_opt", f"sk_bucket_bits={int(rng.choice([4, 9, 12, 19]))}"]
+            elif path == 3 and ranks > 1:
+                gpu_extra += ["-gpu_opt", "dist_design=1"]
             for name, binary, extra in (("orc", checker, ["-t", "1"]), ("gpu", GPU, gpu_extra)):
                 d = os.path.join(td, name)
                 os.mkdir(d)
@@ -95,7 +104,7 @@ def main():
                 print(f"MISMATCH case {case}: G={G} cov={cov} err={err} RL={RL} args={' '.join(args)} rc={outs['orc'][0]}/{outs['gpu'][0]}", flush=True)
             else:
                 nct = sum(1 for l in open(os.path.join(outs["gpu"][1], "out_contig.fa")) if l.startswith(">")) if outs["gpu"][0] == 0 else -1
-                print(f"case {case}: ok (G={G} cov={cov} err={err} args={' '.join(args)} ranks={ranks} rc={outs['gpu'][0]} records={nct})", flush=True)
+                print(f"case {case}: ok (G={G} cov={cov} err={err} args={' '.join(args)} ranks={ranks} gpu_opts={' '.join(gpu_extra)} rc={outs['gpu'][0]} records={nct})", flush=True)
     print(f"{n_cases} cases, {bad} mismatches")
     sys.exit(1 if bad else 0)
 
