@@ -15,6 +15,8 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+from typing import Optional
+
 import numpy as np
 
 
@@ -73,7 +75,7 @@ def exchange_records_split(dist, torch, keys, counts16, n_single, n_multi, W: in
     return rk, rcnt, recv
 
 
-def count_exchanging_records(g, dist, world: int, rank: int, k: int):
+def count_exchanging_records(g, dist, world: int, rank: int, k: int, laps: Optional[dict] = None):
     """The N > 1 counting step with the exchange BEFORE the counting (k <= 32, world a power of two): every rank cuts its reads into
     16-byte run records grouped by owner rank (owner = top bits of the minimizer bucket), ONE all_to_all moves them, every rank counts
     what it received.  No export and no owner-side merge: copies of a run from different ranks meet in the bucket kernel's record
@@ -86,6 +88,16 @@ def count_exchanging_records(g, dist, world: int, rank: int, k: int):
     gloo = dist.get_backend() == "gloo"
     dev = torch.device("cuda", torch.cuda.current_device())
     cdev = torch.device("cpu") if gloo else dev
+    import time
+    t_last = [time.perf_counter()]
+
+    def lap(name):                                      # (development: wall time per section, device work included)
+        if laps is not None:
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            laps[name] = laps.get(name, 0.0) + (t - t_last[0]) * 1e3
+            t_last[0] = t
+
     n_reads, n_bases = g.reads_info()
     if world & (world - 1):
         raise ValueError("count_exchanging_records needs a power-of-two number of ranks")
@@ -100,14 +112,18 @@ def count_exchanging_records(g, dist, world: int, rank: int, k: int):
     local_bits = memo[1]
     counts = (C.c_uint64 * n_owners)()
     nw = C.c_uint64()
+    lap("bits")
     g._chk(lib.pb_sk_owner_records(h, k, n_owners, local_bits, counts, C.byref(nw)))
+    lap("owner_records")
     send = [int(x) for x in counts] if world > 1 else [sum(int(x) for x in counts)]
     sc = torch.tensor(send, dtype=torch.int64, device=cdev)
     rc = torch.empty(world, dtype=torch.int64, device=cdev)
     dist.all_to_all_single(rc, sc)
     recv = [int(x) for x in rc.tolist()]
+    lap("sizes")
     sbuf = torch.empty(max(sum(send), 1) * 16, dtype=torch.uint8, device=dev)
     g._chk(lib.pb_sk_owner_records_copy(h, C.c_void_p(sbuf.data_ptr())))        # (an owner's records lie in one region per XCD: packed here)
+    lap("pack")
     if gloo:                                            # gloo has no all_to_all on device tensors: staged through the host (tests)
         rb = torch.empty(max(sum(recv), 1) * 16, dtype=torch.uint8)
         dist.all_to_all_single(rb[:sum(recv) * 16], sbuf[:sum(send) * 16].cpu(), [r * 16 for r in recv], [s * 16 for s in send])
@@ -116,9 +132,11 @@ def count_exchanging_records(g, dist, world: int, rank: int, k: int):
         rbuf = torch.empty(max(sum(recv), 1) * 16, dtype=torch.uint8, device=dev)
         dist.all_to_all_single(rbuf[:sum(recv) * 16], sbuf[:sum(send) * 16], [r * 16 for r in recv], [s * 16 for s in send])
     torch.cuda.synchronize()                 # the library runs on its own stream
+    lap("exchange")
     hist = np.zeros(PB_OCC_BINS, dtype=np.uint64)
     mx, nd = C.c_uint64(), C.c_uint64()
     g._chk(lib.pb_sk_count_records(h, k, C.c_void_p(rbuf.data_ptr()), sum(recv), local_bits, hist.ctypes.data, C.byref(mx), C.byref(nd)))
+    lap("count_records")
     both = np.empty(PB_OCC_BINS + 2, dtype=np.int64)
     both[:PB_OCC_BINS] = hist.astype(np.int64)
     both[PB_OCC_BINS] = nd.value
@@ -134,6 +152,7 @@ def count_exchanging_records(g, dist, world: int, rank: int, k: int):
     g.n_distinct = int(tot[PB_OCC_BINS])
     g.n_instances = int(tot[PB_OCC_BINS + 1])
     g.records_sent, g.records_received = sum(send), sum(recv)
+    lap("histogram")
     return g.occ_hist
 
 

@@ -41,6 +41,10 @@ def main():
         label = {"count": "count only                          ", "counts": "count + exchange of (key,count) + merge", "records": "exchange of run records, then count   "}[mode]
         extra = f"  (part1 {g.kernel_ms('part1'):.2f} + scatter / bucket {g.kernel_ms('count_records'):.2f} ms of kernels)" if mode == "records" else ""
         print(label, " ".join(f"{t:7.2f}" for t in ts), "ms" + extra, flush=True)
+    laps = {}
+    for _ in range(4):
+        count_exchanging_records(g, dist, 1, 0, 32, laps=laps)
+    print("sections of the records design (ms per step, a device synchronisation after each):", {k: round(v / 4, 3) for k, v in laps.items()}, flush=True)
     dist.destroy_process_group()
 
 
