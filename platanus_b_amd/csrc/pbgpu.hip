@@ -255,6 +255,7 @@ static inline unsigned grid_for(u64 n, unsigned block, unsigned max_blocks = 256
 
 #include "kernels_count.inc"
 #include "kernels_superk.inc"
+#include "kernels_superk2.inc"
 #include "kernels_sort.inc"
 
 // ------------------------------------------------------------------------------------------------------
@@ -779,6 +780,92 @@ static int count_superk(pb_ctx *ctx, unsigned k, bool *done, bool want_pos = fal
     return PB_OK;
 }
 
+// Super-k-mer pass for two-word keys (33 <= k <= 64; kernels_superk2.inc).  *done = false: something did not fit (the caller takes the
+// direct pass); there is no partial result.
+static int count_superk2(pb_ctx *ctx, unsigned k, bool *done)
+{
+    int rc;
+    *done = false;
+    const u64 lost = (u64)k * ctx->n_reads;
+    const u64 windows = ctx->stream_len > lost + 4096 ? ctx->stream_len - lost : ctx->stream_len;
+    Sk2Params p;
+    memset(&p, 0, sizeof(p));
+    p.k = k;
+    p.m = k - (SK2_WIN - 1);
+    // ~2 * SK2_SLOTS windows per final bucket: at sequencing depth that is a third of the table in distinct keys
+    unsigned B = 8;
+    while (((u64)(SK2_SLOTS * 2) << B) < windows && B < SK_MAX_B) ++B;
+    if (ctx->sk_force_bits >= 2 && ctx->sk_force_bits <= SK_MAX_B) B = (unsigned)ctx->sk_force_bits;
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        p.B = B;
+        p.l1 = std::max(B / 2, B > 9 ? B - 9 : 0u);
+        p.l2 = B - p.l1;
+        p.nx = PB_XCD;
+        const double est_rec = (double)windows * 2.0 / (SK2_WIN + 1.0) + 2.0 * (double)ctx->n_reads;
+        const u64 nb1 = (1ull << p.l1) * PB_XCD, nb2 = 1ull << B;
+        p.cap1 = (u64)(est_rec / (double)nb1 * 1.5) + 4096;
+        p.cap2 = (u32)std::min<double>(est_rec / (double)nb2 * (attempt ? 6.0 : 3.0) + 256.0, 1e9);
+        if ((rc = ensure(ctx, ctx->part_bucket1, nb1 * p.cap1 * 24)) != PB_OK) return rc;
+        if ((rc = ensure(ctx, ctx->part_bucket2, nb2 * (u64)p.cap2 * 24)) != PB_OK) return rc;
+        if ((rc = ensure(ctx, ctx->part_meta, (nb1 * SK_CUR1_STRIDE + nb2) * 4)) != PB_OK) return rc;
+        p.bucket1 = (u64 *)ctx->part_bucket1.p;
+        p.bucket2 = (u64 *)ctx->part_bucket2.p;
+        p.cursor1 = (u32 *)ctx->part_meta.p;
+        p.cursor2 = p.cursor1 + nb1 * SK_CUR1_STRIDE;
+        p.scalars = (u64 *)ctx->d_scalars.p;
+        const u64 out_cap = std::min<u64>(std::max<u64>(ctx->stream_len, 1), nb2 * (u64)SK2_SLOT_LIMIT);
+        if ((rc = ensure(ctx, ctx->dist_keys, out_cap * 16)) != PB_OK) return rc;
+        if ((rc = ensure(ctx, ctx->dist_counts, out_cap * 4)) != PB_OK) return rc;
+        HIPCHK(hipMemsetAsync(ctx->d_scalars.p, 0, 16 * 8, ctx->stream));
+        HIPCHK(hipMemsetAsync(ctx->part_meta.p, 0, (nb1 * SK_CUR1_STRIDE + nb2) * 4, ctx->stream));
+        u64 sc[9];
+        {
+            LazyTimer t1(ctx, "part1", 0);
+            const u64 n_tiles = (ctx->stream_len + SK2_OWN - 1) / SK2_OWN;
+            const size_t dig_bytes = (size_t)2 * 4 * (1u << p.l1);
+            const u64 nw64 = (ctx->stream_len + 63) / 64 + PB_STREAM_PAD_WORDS64;
+            sk2_part1_kernel<<<grid_for(n_tiles, 1, 256 * 16), SK1_THREADS, dig_bytes, ctx->stream>>>((const u64 *)ctx->packed.p, cur_mask(ctx), ctx->stream_len, nw64, p);
+            t1.stop();
+            LazyTimer t2(ctx, "part2", 1);
+            const u64 exp_tiles = (u64)(est_rec / (double)nb1) / SK2P_RCAP + 1;
+            const unsigned blocks_per_sub = (unsigned)std::min<u64>(std::max<u64>(exp_tiles / 4, 1), 64);
+            sk2_part2_kernel<<<dim3(blocks_per_sub, (unsigned)nb1), SK_THREADS, 0, ctx->stream>>>(p);
+            t2.stop();
+            LazyTimer t3(ctx, "bucket", 2);
+            sk2_bucket_kernel<<<grid_for(nb2, 1, 256 * 16), SK2_BUCKET_THREADS, 0, ctx->stream>>>(p, (u64 *)ctx->dist_keys.p, (u32 *)ctx->dist_counts.p, out_cap);
+            t3.stop();
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(sc, ctx->d_scalars.p, 72, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            t1.read(); t2.read(); t3.read();
+        }
+        if (ctx->opt_verbose)
+            fprintf(stderr, "[pbgpu] super-k-mer pass (two-word keys): k %u, m %u, 2^%u buckets (l1 %u), cap1 %llu cap2 %u: windows %llu, records %llu, distinct %llu, misfit %llu\n", k, p.m, B,
+                    p.l1, (unsigned long long)p.cap1, p.cap2, (unsigned long long)sc[0], (unsigned long long)sc[6], (unsigned long long)sc[4], (unsigned long long)sc[1]);
+        if (sc[1] == 0) {
+            ctx->n_instances = sc[0];
+            ctx->n_distinct = sc[4];
+            ctx->hist_done = 0;
+            ctx->h_hist_valid = false;
+            ctx->sk_records = sc[6];
+            ctx->sk_bits = B;
+            ctx->sk_flagged = ctx->sk_spilled = 0;
+            ctx->stage_ms["sk_bucket_bits"] = (float)B;
+            ctx->stage_ms["sk_flagged_buckets"] = 0.f;
+            ctx->stage_ms["sk_spilled_records"] = 0.f;
+            ctx->stage_ms["sk_records_per_1k_windows"] = sc[0] ? (float)(1000.0 * (double)sc[6] / (double)sc[0]) : 0.f;
+            ctx->stage_ms["seg_compact"] = ctx->stage_ms["compact"] = 0.f;
+            ctx->stage_ms["count"] = ctx->stage_ms["part1"] + ctx->stage_ms["part2"] + ctx->stage_ms["bucket"];
+            *done = true;
+            return PB_OK;
+        }
+        if (ctx->sk_force_bits || B + 2 > SK_MAX_B) break;           // a sub-stream, a bucket or a table was too small: once more with 4x the buckets
+        B += 2;
+    }
+    ctx->stage_ms["part1"] = ctx->stage_ms["part2"] = ctx->stage_ms["bucket"] = 0.f;
+    return PB_OK;
+}
+
 // scratch[2] (keys, n * W words) and scratch[3] (u32 counts) -> ctx->ret_keys / ret_counts, ascending by the 2k-bit key value
 // (counter.h:916-951 std::sort); the sorted set becomes the context's retained set
 static int sort_retained(pb_ctx *ctx, u64 n)
@@ -1036,11 +1123,11 @@ int pb_count(pb_ctx *ctx, unsigned k, uint64_t *occ_hist, uint64_t *max_occ, uin
     if ((rc = ensure(ctx, ctx->d_scalars, 16 * 8)) != PB_OK) return rc;
     bool done = false;
     // small inputs take the direct pass unless pb_set_option("count_path") says otherwise
-    const bool want_sk = ctx->W == 1 && ctx->stream_len >= k &&
+    const bool want_sk = k <= 64 && ctx->stream_len >= k &&
                          (ctx->opt_count_path ? ctx->opt_count_path == 2 : ctx->stream_len >= (1ull << 22));
     ctx->sk_records = 0;
     if (want_sk) {
-        if ((rc = count_superk(ctx, k, &done)) != PB_OK) return rc;
+        if ((rc = ctx->W == 1 ? count_superk(ctx, k, &done) : count_superk2(ctx, k, &done)) != PB_OK) return rc;
     }
     if (!done) {
         switch (ctx->W) {

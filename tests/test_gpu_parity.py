@@ -511,6 +511,31 @@ def test_superkmer_count_path_matches_oracle(k, gpu, oracle_built, monkeypatch):
     _superk_case(gpu, oracle_built, np.concatenate([r1, r2]), k, must_take_path=k >= 9)
 
 
+@pytest.mark.parametrize("k", [33, 34, 40, 45, 47, 48, 51, 52, 63, 64])
+def test_superkmer_two_word_keys(k, gpu, oracle_built, monkeypatch):
+    """33 <= k <= 64 through the super-k-mer pass for two-word keys (kernels_superk2.inc: minimizers of k - 19 bases hashed on both
+    strands, 24-byte records, claim-through-the-count-word table of two-word keys) against the oracle: histogram, max_occ, the
+    retained (key,count) sets.  k = 33 / 64 are the ends of the range, 47 / 48 / 51 / 52 sit around the 32-base minimizer and the
+    record's word boundaries; reads carry N bases."""
+    from platanus_b_amd import synth
+    monkeypatch.setitem(GpuCounter.default_options, "count_path", COUNT_PATH["superk"])
+    r1, r2 = synth.make_reads(60_000, 40, seed=300 + k, n_rate=0.002)
+    _superk_case(gpu, oracle_built, np.concatenate([r1, r2]), k)
+
+
+def test_superkmer_two_word_keys_misfits_fall_back(gpu, oracle_built, monkeypatch):
+    """Poly-A and dinucleotide reads put most records into a few buckets: the two-word pass has no partial fallback, it reports the
+    misfit and the direct pass counts the input (same results).  Reads shorter than k contribute nothing."""
+    from platanus_b_amd import synth
+    monkeypatch.setitem(GpuCounter.default_options, "count_path", COUNT_PATH["superk"])
+    r1, r2 = synth.make_reads(20_000, 30, seed=377)
+    poly = np.zeros((3000, 150), dtype=np.uint8)
+    di = np.tile(np.array([1, 2], dtype=np.uint8), (250, 75))
+    _superk_case(gpu, oracle_built, np.concatenate([r1, poly, di, r2]), 45, cutoffs=(2,), must_take_path=False)
+    short = synth.make_reads(20_000, 10, seed=378, read_len=40)[0]
+    _superk_case(gpu, oracle_built, short, 45, cutoffs=(1,), must_take_path=False)
+
+
 @pytest.mark.parametrize("bits", [2, 9, 15, 18, 19, 20])
 def test_superkmer_other_bucket_counts(bits, gpu, oracle_built, monkeypatch):
     """4 .. 2^20 minimizer buckets: 4 buckets overflow their LDS tables and go through the global table, 2^18 is what a
