@@ -13,7 +13,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-GPU = os.path.join(ROOT, "platanus_b_amd", "bin", "platanus_b")
+GPU = os.environ.get("PB_GPU_BIN") or os.path.join(ROOT, "platanus_b_amd", "bin", "platanus_b")     # (PB_GPU_BIN: e.g. an AddressSanitizer build of the host)
 ORC = os.path.join(ROOT, "oracle", "pb_oracle")
 REF = os.path.join(ROOT, "oracle", "_ref", "platanus_b")
 

