@@ -83,6 +83,24 @@ def test_cli_n_ranks_write_the_reference_files(world, name, run, manifest, tmp_p
             assert filecmp.cmp(tmp_path / fn, gold, shallow=False), fn
 
 
+@pytest.mark.parametrize("ranks", [1, 2])
+def test_cli_k0_above_32_through_the_two_word_super_kmer_pass(ranks, manifest, tmp_path):
+    """`assemble -k 45`: the first counting pass through kernels_superk2.inc (forced with -gpu_opt count_path=2: the golden input is below
+    the size at which it is the default), one rank and two (count per rank + owner merge of two-word keys): the reference's files."""
+    case = manifest["k45"]
+    info = case["runs"]["multik_k45"]
+    from platanus_b_amd import synth
+    synth.write_pair_files(str(tmp_path / "in"), case["genome"], case["cov"], case["seed"], err=case["err"], n_rate=case["n_rate"], het=case.get("het", 0.0))
+    extra = ["-gpus", str(ranks), "-share_gpu"] if ranks > 1 else []
+    p = subprocess.run([BIN, "assemble", *info["args"], *extra, "-gpu_opt", "count_path=2", "-gpu_opt", "verbose=1", "-o", "out", "-f", "in_1.fq", "in_2.fq"],
+                       cwd=tmp_path, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert "super-k-mer pass (two-word keys): k 45" in p.stderr and "misfit 0" in p.stderr, p.stderr[-3000:]
+    for fn, meta in info["files"].items():
+        assert (tmp_path / fn).exists(), fn
+        assert _md5(tmp_path / fn) == meta["md5"], fn
+
+
 @pytest.mark.parametrize("world,name,run", [(2, "c2", "multik_n2"), (4, "c1", "multik"), (2, "het", "u1")])
 def test_cli_n_ranks_exchanging_run_records(world, name, run, manifest, tmp_path):
     """The same with the k0 counting done the other way round (pb_dist_count: run records grouped by the owner of their minimizer
