@@ -173,7 +173,7 @@ class GpuCounter:
 
     # ---- counter.h:154 makeKmerReadDistributionMT ---------------------------------------------------
     def make_kmer_read_distribution(self, k: int):
-        hist = np.zeros(PB_OCC_BINS, dtype=np.uint64)
+        hist = np.empty(PB_OCC_BINS, dtype=np.uint64)          # (pb_count writes every bin)
         mx, ni, nd = C.c_uint64(), C.c_uint64(), C.c_uint64()
         self._chk(self.lib.pb_count(self.h, k, hist.ctypes.data, C.byref(mx), C.byref(ni), C.byref(nd)))
         self.k, self.occ_hist, self.max_occ = k, hist, mx.value

@@ -522,7 +522,8 @@ static int finish_count(pb_ctx *ctx, uint64_t *occ_hist, uint64_t *max_occ)
         h = hv.data();
     }
     ctx->h_hist_valid = false;
-    if (occ_hist) for (int i = 0; i < PB_OCC_BINS; ++i) occ_hist[i] = h[i];
+    static_assert(sizeof(uint64_t) == sizeof(u64), "histogram bins are 64-bit");
+    if (occ_hist) memcpy(occ_hist, h, (size_t)PB_OCC_BINS * 8);
     if (max_occ) { *max_occ = 0; for (int i = PB_COUNT_MAX; i > 0; --i) if (h[i]) { *max_occ = (u64)i; break; } }
     return PB_OK;
 }
