@@ -12,6 +12,7 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 
@@ -103,7 +104,8 @@ inline void read_file(const std::string &path, std::vector<ParsedPiece> &pieces,
     else if (got_magic == 3 && magic[0] == 'B' && magic[1] == 'Z' && magic[2] == 'h') { fclose(fp); fp = popen(("bzip2 -cd " + path).c_str(), "r"); piped = true; }
     else rewind(fp);
     if (!fp) throw file_error(path);
-    std::string buf;
+    char *raw = nullptr;
+    struct FreeRaw { char *&p; ~FreeRaw() { free(p); } } free_raw{raw};
     const char *data = nullptr;
     size_t size = 0;
     void *map = MAP_FAILED;
@@ -115,11 +117,35 @@ inline void read_file(const std::string &path, std::vector<ParsedPiece> &pieces,
         }
     }
     if (map == MAP_FAILED) {
-        std::vector<char> chunk(16u << 20);
-        size_t got;
-        while ((got = fread(chunk.data(), 1, chunk.size(), fp)) > 0) buf.append(chunk.data(), got);
-        data = buf.data();
-        size = buf.size();
+        // a pipe (or a file that cannot be mapped): read straight into the final buffer.  A gzip file says how large that is in its last
+        // four bytes (ISIZE, modulo 2^32: a hint, not a promise), so the buffer does not grow by copying itself a dozen times
+        size_t expect = 64u << 20;
+        if (piped && magic[0] == 0x1f) {
+            if (FILE *g = fopen(path.c_str(), "rb")) {
+                unsigned char t[4];
+                if (fseek(g, -4, SEEK_END) == 0 && fread(t, 1, 4, g) == 4) expect = ((size_t)t[0] | ((size_t)t[1] << 8) | ((size_t)t[2] << 16) | ((size_t)t[3] << 24)) + (1u << 16);
+                fclose(g);
+            }
+        }
+#ifdef F_SETPIPE_SZ
+        if (piped) (void)fcntl(fileno(fp), F_SETPIPE_SZ, 1 << 20);      // (fewer wake-ups of the decompressor)
+#endif
+        size_t cap = expect, have = 0, got;
+        raw = (char *)malloc(cap);                                   // (not value-initialised: the pages are touched once, by fread)
+        if (!raw) throw std::bad_alloc();
+        for (;;) {
+            if (have == cap) {
+                cap += cap / 2;
+                char *grown = (char *)realloc(raw, cap);
+                if (!grown) { free(raw); raw = nullptr; throw std::bad_alloc(); }
+                raw = grown;
+            }
+            got = fread(raw + have, 1, cap - have, fp);
+            if (got == 0) break;
+            have += got;
+        }
+        data = raw;
+        size = have;
     }
     if (piped) pclose(fp); else fclose(fp);
     struct Unmap { void *m; size_t n; ~Unmap() { if (m != MAP_FAILED) munmap(m, n); } } unmap{map, size};
