@@ -137,20 +137,22 @@ def count_exchanging_records(g, dist, world: int, rank: int, k: int, laps: Optio
     mx, nd = C.c_uint64(), C.c_uint64()
     g._chk(lib.pb_sk_count_records(h, k, C.c_void_p(rbuf.data_ptr()), sum(recv), local_bits, hist.ctypes.data, C.byref(mx), C.byref(nd)))
     lap("count_records")
-    both = np.empty(PB_OCC_BINS + 2, dtype=np.int64)
-    both[:PB_OCC_BINS] = hist.astype(np.int64)
-    both[PB_OCC_BINS] = nd.value
-    both[PB_OCC_BINS + 1] = nw.value
-    th = torch.from_numpy(both).to(cdev)
+    # global histogram: the ranks first agree on the largest count anybody saw (one gather of three numbers per rank, which also sums
+    # the distinct and window counts), then all-reduce only the bins up to it -- a few KB instead of the 65,535 bins
+    mine = torch.tensor([mx.value, nd.value, nw.value], dtype=torch.int64, device=cdev)
+    every = torch.empty(3 * world, dtype=torch.int64, device=cdev)
+    dist.all_gather_into_tensor(every, mine)
+    ev = every.cpu().numpy().reshape(world, 3)
+    top = int(ev[:, 0].max())
+    th = torch.from_numpy(hist[:top + 1].astype(np.int64)).to(cdev)
     dist.all_reduce(th)
-    tot = th.cpu().numpy()
     g.k = k
-    g.occ_hist = tot[:PB_OCC_BINS].astype(np.uint64)
-    nz = np.nonzero(g.occ_hist[1:65535])[0]
-    g.max_occ = int(nz[-1]) + 1 if nz.size else 0
+    g.occ_hist = np.zeros(PB_OCC_BINS, dtype=np.uint64)
+    g.occ_hist[:top + 1] = th.cpu().numpy().astype(np.uint64)
+    g.max_occ = top
     g.n_distinct_local = nd.value
-    g.n_distinct = int(tot[PB_OCC_BINS])
-    g.n_instances = int(tot[PB_OCC_BINS + 1])
+    g.n_distinct = int(ev[:, 1].sum())
+    g.n_instances = int(ev[:, 2].sum())
     g.records_sent, g.records_received = sum(send), sum(recv)
     lap("histogram")
     return g.occ_hist

@@ -523,6 +523,16 @@ def test_superkmer_two_word_keys(k, gpu, oracle_built, monkeypatch):
     _superk_case(gpu, oracle_built, np.concatenate([r1, r2]), k)
 
 
+def test_superkmer_two_word_keys_low_coverage_repeats_with_more_buckets(gpu, oracle_built, monkeypatch):
+    """2x coverage, 2 % errors, k = 40: nearly every window is a distinct key, several times what the tables of the first attempt hold --
+    the pass reports the misfit, repeats itself with 4x the buckets and must then give the oracle's answer through its own kernels."""
+    from platanus_b_amd import synth
+    monkeypatch.setitem(GpuCounter.default_options, "count_path", COUNT_PATH["superk"])
+    r1, r2 = synth.make_reads(300_000, 2, seed=391, err=0.02)
+    g = _superk_case(gpu, oracle_built, np.concatenate([r1, r2]), 40, cutoffs=(1,))
+    assert g.kernel_ms("sk_bucket_bits") >= 10
+
+
 def test_superkmer_two_word_keys_misfits_fall_back(gpu, oracle_built, monkeypatch):
     """Poly-A and dinucleotide reads put most records into a few buckets: the two-word pass has no partial fallback, it reports the
     misfit and the direct pass counts the input (same results).  Reads shorter than k contribute nothing."""
