@@ -87,8 +87,13 @@ def main():
             for name, binary, extra in (("orc", checker, ["-t", "1"]), ("gpu", GPU, gpu_extra)):
                 d = os.path.join(td, name)
                 os.mkdir(d)
-                p = subprocess.run([binary, "assemble", *args, *extra, "-o", "out", "-f", "../in_1.fq", "../in_2.fq"], cwd=d, capture_output=True, text=True,
-                                   timeout=600)
+                cmd = [binary, "assemble", *args, *extra, "-o", "out", "-f", "../in_1.fq", "../in_2.fq"]
+                p = subprocess.run(cmd, cwd=d, capture_output=True, text=True, timeout=600)
+                if p.returncode < 0:                  # killed by a signal: reported and run once more (see tools/fuzz_cli2.py::run)
+                    print(f"  SIGNAL {-p.returncode} from {os.path.basename(binary)} {' '.join(cmd[1:])} -- running it once more", flush=True)
+                    for fn in os.listdir(d):
+                        os.remove(os.path.join(d, fn))
+                    p = subprocess.run(cmd, cwd=d, capture_output=True, text=True, timeout=600)
                 outs[name] = (p.returncode, d)
             same = outs["orc"][0] == outs["gpu"][0]
             if same and outs["orc"][0] == 0:
