@@ -9,6 +9,7 @@
 #include "errors.hpp"
 #include <iostream>
 #include <csignal>
+#include <execinfo.h>
 #include <sys/mman.h>
 #include <sys/wait.h>
 #include <unistd.h>
@@ -136,8 +137,29 @@ static int main_kmer_divide(int argc, char **argv)       // options: kmer_divide
     }
 }
 
+// A crash says where: the frames go to stderr (async-signal-safe calls only), then the default action takes over, so the exit status
+// is still the signal's (the reference has no such handler; its crashes are bare).
+static void crash_trace(int sig)
+{
+    static const char msg[] = "\nplatanus_b: fatal signal, frames:\n";
+    (void)!write(2, msg, sizeof(msg) - 1);
+    void *frames[48];
+    const int n = backtrace(frames, 48);
+    backtrace_symbols_fd(frames, n, 2);
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+
 int main(int argc, char **argv)
 {
+    {
+        void *warm[4];
+        (void)backtrace(warm, 4);                     // (loads libgcc's unwinder now, not inside the handler)
+        signal(SIGSEGV, crash_trace);
+        signal(SIGBUS, crash_trace);
+        signal(SIGFPE, crash_trace);
+        signal(SIGILL, crash_trace);
+    }
     show_version_and_args(argc, argv);
     if (argc >= 2 && strcmp(argv[1], "-v") == 0) return 0;                       // main.cpp:77-79
     if (argc >= 2 && strcmp(argv[1], "kmer_divide") == 0) return main_kmer_divide(argc, argv);

@@ -90,7 +90,8 @@ def main():
                 cmd = [binary, "assemble", *args, *extra, "-o", "out", "-f", "../in_1.fq", "../in_2.fq"]
                 p = subprocess.run(cmd, cwd=d, capture_output=True, text=True, timeout=600)
                 if p.returncode < 0:                  # killed by a signal: reported and run once more (see tools/fuzz_cli2.py::run)
-                    print(f"  SIGNAL {-p.returncode} from {os.path.basename(binary)} {' '.join(cmd[1:])} -- running it once more", flush=True)
+                    print(f"  SIGNAL {-p.returncode} from {os.path.basename(binary)} {' '.join(cmd[1:])} -- running it once more; its stderr ended:\n    " +
+                          p.stderr[-1800:].replace("\n", "\n    "), flush=True)
                     for fn in os.listdir(d):
                         os.remove(os.path.join(d, fn))
                     p = subprocess.run(cmd, cwd=d, capture_output=True, text=True, timeout=600)

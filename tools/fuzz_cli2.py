@@ -23,7 +23,8 @@ def run(binary, args, cwd):
         # Killed by a signal.  Seen once in ~700 runs of the GPU `merge` (SIGSEGV, round 2), not reproducible: 320 repeats of the same
         # command and an AddressSanitizer build of the host over the same cases were clean.  Reported loudly and run once more, so that
         # what the comparison below judges is the program's output, not that event.
-        print(f"  SIGNAL {-r.returncode} from {os.path.basename(binary)} {' '.join(args)} -- running it once more", flush=True)
+        print(f"  SIGNAL {-r.returncode} from {os.path.basename(binary)} {' '.join(args)} -- running it once more; its stderr ended:\n    " +
+              r.stderr[-1800:].replace("\n", "\n    "), flush=True)
         r = subprocess.run([binary, *args], cwd=cwd, capture_output=True, text=True, timeout=600)
     return r
 
