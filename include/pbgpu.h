@@ -153,6 +153,9 @@ int pb_dist_detach(pb_ctx *ctx);
 int pb_dist_info(const pb_ctx *ctx, int *rank, int *world, int *rccl);
 int pb_dist_barrier(pb_ctx *ctx);
 int pb_dist_allreduce_u64(pb_ctx *ctx, uint64_t *buf, uint64_t n);
+/* the RCCL calls behind the functions below, with this rank as its own peer (n_bytes sent and received in one group, compared): what a
+ * one-GPU box can check of the RCCL data path */
+int pb_dist_rccl_selftest(pb_ctx *ctx, uint64_t n_bytes);
 int pb_dist_merge_counts(pb_ctx *ctx, uint64_t *occ_hist, uint64_t *max_occ, uint64_t *n_distinct);
 /* pb_count over all ranks' reads in one call: for k <= 32 and a power-of-two number of ranks the run records are exchanged BEFORE they are
  * counted (pb_sk_owner_records / pb_sk_count_records: no export, no merge); otherwise pb_count + pb_dist_merge_counts */

@@ -523,6 +523,25 @@ def test_superkmer_two_word_keys(k, gpu, oracle_built, monkeypatch):
     _superk_case(gpu, oracle_built, np.concatenate([r1, r2]), k)
 
 
+def test_dist_rccl_calls_with_the_rank_as_its_own_peer(gpu):
+    """csrc/dist.inc talks to RCCL through dlopen (no link-time dependency): symbols, the unique id passed by value, the datatype constant,
+    group calls and the library's stream can be checked on one GPU with a communicator of one rank that sends to and receives from
+    itself (pb_dist_rccl_selftest).  More than one rank needs more than one device: the driver's N > 1 runs."""
+    import ctypes as C
+    g = gpu(0)
+    lib = g.lib
+    lib.pb_dist_shared_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    lib.pb_dist_attach.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    lib.pb_dist_rccl_selftest.argtypes = [C.c_void_p, C.c_uint64]
+    lib.pb_dist_detach.argtypes = [C.c_void_p]
+    shared = C.c_void_p()
+    assert lib.pb_dist_shared_create(1, C.byref(shared)) == 0
+    g._chk(lib.pb_dist_attach(g.h, shared, 0, 1, 1))
+    for n in (1, 4096, 3_000_001, 64 << 20):
+        g._chk(lib.pb_dist_rccl_selftest(g.h, n))
+    g._chk(lib.pb_dist_detach(g.h))
+
+
 def test_superkmer_two_word_keys_low_coverage_repeats_with_more_buckets(gpu, oracle_built, monkeypatch):
     """2x coverage, 2 % errors, k = 40: nearly every window is a distinct key, several times what the tables of the first attempt hold --
     the pass reports the misfit, repeats itself with 4x the buckets and must then give the oracle's answer through its own kernels."""
