@@ -552,9 +552,22 @@ def test_superkmer_two_word_keys_low_coverage_repeats_with_more_buckets(gpu, ora
     assert g.kernel_ms("sk_bucket_bits") >= 10
 
 
+def test_superkmer_two_word_keys_flagged_buckets_through_the_global_table(gpu, oracle_built, monkeypatch):
+    """A 21 kbp tandem repeat of a 7-mer inside a random genome, k = 45: the repeat's windows share a handful of minimizers, their buckets
+    overflow, the records go to the spill list and sk2_flagged_kernel counts the flagged buckets through the global table -- the pass
+    itself must finish (no hand-over to the direct pass) with the oracle's answer."""
+    from platanus_b_amd import synth
+    monkeypatch.setitem(GpuCounter.default_options, "count_path", COUNT_PATH["superk"])
+    genome = synth.make_genome(80_000, 5)
+    genome[30_000:51_000] = np.resize(np.array([0, 1, 2, 3, 3, 2, 0], dtype=np.uint8), 21_000)
+    r1, r2 = synth.make_reads(80_000, 40, seed=395, genome=genome, n_rate=0.001)
+    g = _superk_case(gpu, oracle_built, np.concatenate([r1, r2]), 45, cutoffs=(2,))
+    assert g.kernel_ms("sk_spilled_records") + g.kernel_ms("sk_flagged_buckets") > 0
+
+
 def test_superkmer_two_word_keys_misfits_fall_back(gpu, oracle_built, monkeypatch):
-    """Poly-A and dinucleotide reads put most records into a few buckets: the two-word pass has no partial fallback, it reports the
-    misfit and the direct pass counts the input (same results).  Reads shorter than k contribute nothing."""
+    """Poly-A and dinucleotide reads put most records into a few buckets: spill list and global table take them, or -- when the spill
+    list itself overflows -- the direct pass counts the input (same results either way).  Reads shorter than k contribute nothing."""
     from platanus_b_amd import synth
     monkeypatch.setitem(GpuCounter.default_options, "count_path", COUNT_PATH["superk"])
     r1, r2 = synth.make_reads(20_000, 30, seed=377)
