@@ -16,7 +16,7 @@ if sys.argv[1] == "--one":
             g.make_kmer_read_distribution(k)
         except Exception as e:
             pass
-    print(sys.argv[3], "part1 %.3f part2 %.3f bucket %.3f" % (g.kernel_ms("part1"), g.kernel_ms("part2"), g.kernel_ms("bucket")), flush=True)
+    print(sys.argv[3], "part1 %.3f part2 %.3f bucket %.3f flagged-path %.3f count %.3f | bits %d flagged %d spilled %d" % (g.kernel_ms("part1"), g.kernel_ms("part2"), g.kernel_ms("bucket"), g.kernel_ms("seg_compact"), g.kernel_ms("count"), g.kernel_ms("sk_bucket_bits"), g.kernel_ms("sk_flagged_buckets"), g.kernel_ms("sk_spilled_records")), flush=True)
 else:
     for lib in sys.argv[2:]:
         subprocess.run([sys.executable, __file__, "--one", sys.argv[1], lib])
