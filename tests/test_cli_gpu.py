@@ -95,7 +95,7 @@ def test_cli_k0_above_32_through_the_two_word_super_kmer_pass(ranks, manifest, t
     p = subprocess.run([BIN, "assemble", *info["args"], *extra, "-gpu_opt", "count_path=2", "-gpu_opt", "verbose=1", "-o", "out", "-f", "in_1.fq", "in_2.fq"],
                        cwd=tmp_path, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
-    assert "super-k-mer pass (two-word keys): k 45" in p.stderr and "misfit 0" in p.stderr, p.stderr[-3000:]
+    assert "super-k-mer pass (two-word keys): k 45" in p.stderr and "overflow 0" in p.stderr, p.stderr[-3000:]
     for fn, meta in info["files"].items():
         assert (tmp_path / fn).exists(), fn
         assert _md5(tmp_path / fn) == meta["md5"], fn
