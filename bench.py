@@ -18,7 +18,8 @@ Reads are packed on the device before the timed region (inputs resident in HBM).
 (the real reference binary oracle/_ref/platanus_b on the bench workload itself, counting stage only, timed
 from its own progress lines; falls back to the repo's CPU port when the binary did not travel),
 `end_to_end` (the drop-in CLI on the same FASTQ files, outputs checked against the reference's md5s) and
-`shard_shapes` (the counting pass on what one of the 8 GPUs of configs[3] and configs[4] holds).
+`shard_shapes` (the counting pass on what one of the 8 GPUs of configs[3] and configs[4] holds, and the bench
+workload at k = 45: the two-word variant of the pass beside the direct pass).
 """
 import argparse
 import json
@@ -156,6 +157,28 @@ def shard_shapes():
                      "identities_hold": bool(ok)}
         g.close()
         del g, genome
+    # the bench workload at k = 45: two-word keys (kernels_superk2.inc) beside the direct pass, which must count the same histogram
+    g = GpuCounter(0)
+    genome = synth.make_genome(GENOME, SEED)
+    n_pairs = int(GENOME * COVERAGE) // (2 * READ_LEN)
+    for lo in range(0, n_pairs, 250_000):
+        r1, r2 = synth.make_reads(GENOME, COVERAGE, SEED, genome=genome, pair_lo=lo, pair_hi=min(lo + 250_000, n_pairs))
+        g.reads_append_matrix(r1)
+        g.reads_append_matrix(r2)
+    res = {}
+    for path, opt in (("super_kmer_pass", 2), ("direct_pass", 1)):
+        g.set_option("count_path", opt)
+        ms = []
+        for it in range(3):
+            h = g.make_kmer_read_distribution(45)
+            if it:
+                ms.append(g.kernel_ms("count"))
+        res[path] = (np.asarray(h).copy(), float(np.mean(ms)), g.kernel_ms("part1") > 0)
+    out["configs[1] reads at k = 45 (two-word keys)"] = {
+        "kmer_instances": int(g.n_instances), "distinct_kmers": int(g.n_distinct), "kernel_ms": res["super_kmer_pass"][1], "direct_pass_kernel_ms": res["direct_pass"][1],
+        "kmers_per_s": g.n_instances / (res["super_kmer_pass"][1] * 1e-3), "super_kmer_pass": bool(res["super_kmer_pass"][2]),
+        "histogram_identical_to_direct_pass": bool(np.array_equal(res["super_kmer_pass"][0], res["direct_pass"][0]))}
+    g.close()
     return out
 
 
