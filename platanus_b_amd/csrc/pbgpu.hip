@@ -670,6 +670,7 @@ static int count_superk(pb_ctx *ctx, unsigned k, bool *done, bool want_pos = fal
             const unsigned g1 = grid_for(n_tiles, 1, 256 * 16);
             if (want_pos) sk_part1_kernel<0, true><<<g1, SK1_THREADS, dig_bytes, ctx->stream>>>((const u64 *)ctx->packed.p, cur_mask(ctx), ctx->stream_len, nw64, p);
             else if (k == 32) sk_part1_kernel<32, false><<<g1, SK1_THREADS, dig_bytes, ctx->stream>>>((const u64 *)ctx->packed.p, cur_mask(ctx), ctx->stream_len, nw64, p);
+            else if (k == 31) sk_part1_kernel<31, false><<<g1, SK1_THREADS, dig_bytes, ctx->stream>>>((const u64 *)ctx->packed.p, cur_mask(ctx), ctx->stream_len, nw64, p);   // (the usual odd k)
             else sk_part1_kernel<0, false><<<g1, SK1_THREADS, dig_bytes, ctx->stream>>>((const u64 *)ctx->packed.p, cur_mask(ctx), ctx->stream_len, nw64, p);
             t1.stop();
             LazyTimer t2(ctx, "part2", 1);
