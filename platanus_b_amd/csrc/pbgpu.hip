@@ -657,9 +657,7 @@ static int count_superk(pb_ctx *ctx, unsigned k, bool *done, bool want_pos = fal
         HIPCHK(hipMemsetAsync(ctx->d_hist.p, 0, 65536 * 8, ctx->stream));
         HIPCHK(hipMemsetAsync(ctx->d_scalars.p, 0, 16 * 8, ctx->stream));
         HIPCHK(hipMemsetAsync(ctx->part_meta.p, 0, (nb1 * SK_CUR1_STRIDE + 2 * nb2) * 4, ctx->stream));
-        LazyTimer ti(ctx, "table_init", 3);
-        table_init_kernel<1><<<grid_for(fcap * 2, 256, 256 * 32), 256, 0, ctx->stream>>>(p.fallback.slots, fcap);
-        ti.stop();
+        ctx->stage_ms["table_init"] = 0.f;                         // (the fallback table is initialised only if a flagged bucket needs it, below)
         u64 sc[9];
         {
             // one host synchronisation for the three kernels (the flags are needed before anything else is decided)
@@ -691,7 +689,7 @@ static int count_superk(pb_ctx *ctx, unsigned k, bool *done, bool want_pos = fal
             if (!ctx->h_hist) HIPCHK(hipHostMalloc((void **)&ctx->h_hist, 65536 * 8, hipHostMallocDefault));
             HIPCHK(hipMemcpyAsync(ctx->h_hist, ctx->d_hist.p, 65536 * 8, hipMemcpyDeviceToHost, ctx->stream));   // final unless buckets were flagged
             HIPCHK(hipStreamSynchronize(ctx->stream));
-            t1.read(); t2.read(); t3.read(); ti.read();
+            t1.read(); t2.read(); t3.read();
         }
         if (ctx->opt_verbose)
             fprintf(stderr, "[pbgpu] super-k-mer pass: k %u, 2^%u buckets (l1 %u), cap1 %llu cap2 %u: windows %llu, records %llu, distinct %llu, flagged buckets %llu, "
@@ -746,6 +744,7 @@ static int count_superk(pb_ctx *ctx, unsigned k, bool *done, bool want_pos = fal
         if (want_pos && !all_in_lds) return PB_OK;                 // records that left the LDS path carry no position: the caller takes the probing kernel
         if (!all_in_lds) {
             StageTimer t4(ctx, "seg_compact");                     // (stage name kept for bench.py: flagged buckets through the global table)
+            table_init_kernel<1><<<grid_for(fcap * 2, 256, 256 * 32), 256, 0, ctx->stream>>>(p.fallback.slots, fcap);
             sk_flagged_kernel<<<dim3(grid_for(nb2, 1, 1024), 16), 256, 0, ctx->stream>>>(p);
             HIPCHK(hipGetLastError());
             HIPCHK(hipMemcpyAsync(sc, ctx->d_scalars.p, 72, hipMemcpyDeviceToHost, ctx->stream));
