@@ -119,6 +119,16 @@ def test_cli_n_ranks_exchanging_run_records(world, name, run, manifest, tmp_path
         assert _md5(tmp_path / fn) == meta["md5"], fn
 
 
+def test_cli_gpu_opt_is_checked(tmp_path):
+    """-gpu_opt without NAME=INT is a usage error; an option the library does not know ends the run with its message, not a crash."""
+    from platanus_b_amd import synth
+    synth.write_pair_files(str(tmp_path / "in"), 5000, 20, 3)
+    p = subprocess.run([BIN, "assemble", "-gpu_opt", "count_path", "-o", "out", "-f", "in_1.fq", "in_2.fq"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 1 and "Usage" in p.stderr
+    p = subprocess.run([BIN, "assemble", "-gpu_opt", "no_such_option=1", "-o", "out", "-f", "in_1.fq", "in_2.fq"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert p.returncode not in (0, 1) and p.returncode > 0 and "unknown option" in p.stderr, p.stderr[-500:]
+
+
 def test_cli_n_ranks_refuses_kmer_occ_only(tmp_path):
     from platanus_b_amd import synth
     synth.write_pair_files(str(tmp_path / "in"), 5000, 20, 3)
