@@ -127,6 +127,34 @@ def end_to_end(tmp, f1, f2):
     return out
 
 
+def end_to_end_n_ranks(tmp, world):
+    """BASELINE.json's second metric at N > 1: process wall time of `platanus_b assemble -gpus N` (N fresh processes forked by the CLI, rank r
+    on device r, tables merged by key owner before every graph stage) on the FASTQ files of the (100 N)x set -- the files the ranks
+    of this bench wrote -- beside `-gpus 1` on the same files; every output file of the two runs is compared (no reference md5 exists
+    at this size: the reference needs hours for it).  On a world of one (tests) the N-rank run is two ranks sharing the device."""
+    import glob
+    import hashlib
+    cli = os.path.join(ROOT, "platanus_b_amd", "bin", "platanus_b")
+    if not os.path.exists(cli):
+        return None
+    files = sorted(glob.glob(os.path.join(tmp, "in*_[12].fq")))
+    n_cli, extra = (world, []) if world > 1 else (2, ["-share_gpu"])
+    out = {"input": f"{len(files)} FASTQ files, {sum(os.path.getsize(f) for f in files) / 1e9:.2f} GB, written by the ranks (page cache)",
+           "command": f"platanus_b assemble -k {K} -gpus {n_cli}" + (" -share_gpu" if extra else "") + " (full multi-k)"}
+    md5 = {}
+    for name, tag, args in ((f"assemble_gpus{n_cli}_wall_s", "n", ["-gpus", str(n_cli), *extra]), ("assemble_gpus1_wall_s", "s", [])):
+        t0 = time.perf_counter()
+        r = subprocess.run([cli, "assemble", "-k", str(K), *args, "-o", os.path.join(tmp, tag), "-f", *files], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+        out[name] = time.perf_counter() - t0
+        if r.returncode != 0:
+            out["error"] = f"{name}: exit status {r.returncode}: {r.stderr[-400:]}"
+            return out
+        md5[tag] = {os.path.basename(f)[len(tag) + 1:]: hashlib.md5(open(f, "rb").read()).hexdigest() for f in sorted(glob.glob(os.path.join(tmp, tag + "_*")))}
+    out["output_md5"] = md5["n"]
+    out["outputs_identical_to_the_single_gpu_run"] = bool(md5["n"]) and md5["n"] == md5["s"]
+    return out
+
+
 def shard_shapes():
     """BASELINE configs[3] and [4] at the shape ONE of their 8 GPUs sees (counting pass only, this GPU): the 1/8 read range of
     5 Mbp x 1000x and of 100 Mbp x 100x (12.5x of a 100 Mbp genome: the mostly-distinct regime before the merge).  Checked through
@@ -182,6 +210,19 @@ def shard_shapes():
     return out
 
 
+def self_launch(n):
+    """Start the ranks of an N-GPU run: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py <the same arguments>` as a child process; returns its exit status."""
+    import socket
+    with socket.socket() as s:                   # a port nobody listens on (the rendezvous of a second bench on the same host must not collide)
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    args = [x for x in sys.argv[1:] if x != "--self-launch"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *args]
+    return subprocess.run(cmd).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -194,18 +235,26 @@ def main():
                          "export (key,count) by owner, all_to_all, owner-side merge")
     ap.add_argument("--exchange-with-one-rank", action="store_true", help=argparse.SUPPRESS)      # tests: the N > 1 step on a world of one (RCCL to itself)
     ap.add_argument("--shard-shapes-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--self-launch", action="store_true", help=argparse.SUPPRESS)                 # tests: take the N > 1 launch path with --gpus 1
     a = ap.parse_args()
     if a.shard_shapes_only:
         print(json.dumps(shard_shapes()))
         return
+    if a.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and (a.gpus > 1 or a.self_launch):
+        # `python bench.py --gpus N` as the driver runs it: this process starts the N ranks itself, as a CHILD process (never an exec)
+        # and before torch is imported or anything here has touched the GPU; rank 0's JSON line passes through the inherited stdout
+        # and the exit status is the child's.
+        sys.exit(self_launch(a.gpus))
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N ...")
+        sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus N` (it launches its own ranks) or under "
+                 f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N`")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
@@ -227,6 +276,13 @@ def main():
 
     # this rank's range of read pairs: rank r of a (COVERAGE*world)x set holds pairs [r*P, (r+1)*P)
     pairs_per_rank = int(a.genome * COVERAGE) // (2 * READ_LEN)
+    # N > 1: the end-to-end leg (`platanus_b assemble -gpus N` on FASTQ files, after the ranks have left) needs the (100 N)x set as files;
+    # every rank writes the pairs it generates anyway, in a directory rank 0 names
+    e2e_dir = None
+    if exchanging and not a.no_cpu_baseline:
+        box = [tempfile.mkdtemp(prefix="pb_bench_") if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        e2e_dir = box[0]
     g = GpuCounter(local_rank)
     genome = synth.make_genome(a.genome, SEED)
     chunk = 250_000
@@ -236,6 +292,9 @@ def main():
         r1, r2 = synth.make_reads(a.genome, COVERAGE * world, SEED, genome=genome, pair_lo=lo, pair_hi=hi)
         g.reads_append_matrix(r1)
         g.reads_append_matrix(r2)
+        if e2e_dir:
+            synth.write_fastq(os.path.join(e2e_dir, f"in{rank}_1.fq"), r1, 1, lo, append=lo > lo0)
+            synth.write_fastq(os.path.join(e2e_dir, f"in{rank}_2.fq"), r2, 2, lo, append=lo > lo0)
     n_reads, n_bases = g.reads_info()
 
     def step():
@@ -341,7 +400,7 @@ def main():
                                         "flagged_buckets": parts["seg_compact"], "table_init": float(np.mean(init_ms)),
                                         "table_to_arrays": parts["compact"], "hist": float(np.mean(hist_ms))}},
         }
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not exchanging and not a.no_cpu_baseline:
             g.close()                        # the legs below bring their own contexts (and the reference needs the host's memory)
             tmp = tempfile.mkdtemp(prefix="pb_bench_")
             try:
@@ -363,9 +422,21 @@ def main():
                 out["shard_shapes"] = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": r.stderr[-500:]}
             except Exception as e:
                 out["shard_shapes"] = {"error": str(e)}
-        print(json.dumps(out))
     if dist is not None:
+        # the ranks give the devices back and leave the process group BEFORE the end-to-end leg starts its own processes
+        g.close()
+        torch.cuda.synchronize()
+        dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        if e2e_dir:
+            try:
+                out["end_to_end"] = end_to_end_n_ranks(e2e_dir, world)
+            except Exception as e:
+                out["end_to_end"] = {"error": str(e)}
+            finally:
+                subprocess.run(["rm", "-rf", e2e_dir])
+        print(json.dumps(out))
 
 
 if __name__ == "__main__":

@@ -46,3 +46,23 @@ def test_bench_n_rank_step_on_a_world_of_one(design):
     assert d["n_gpus"] == 1 and d["config"]["torch_distributed"] == {"backend": "nccl", "world_size": 1}
     assert d["value"] > 0 and d["roofline"]["kernel_ms"] > 0
     assert d["config"]["distinct_kmers"] > 200_000
+
+
+def test_bench_starts_its_own_ranks_and_times_the_n_rank_cli():
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment (how the driver's scaling runs call it) starts its ranks itself:
+    a child `python -m torch.distributed.run ...` before anything touches the GPU.  Here N = 1 is forced through the same launch code
+    (--self-launch); the N > 1 step runs on a world of one and the end-to-end leg runs the N-rank CLI (two ranks sharing the device)
+    beside the single-GPU CLI on the FASTQ files the rank wrote, comparing every output file."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--self-launch", "--exchange-with-one-rank", "--genome", "300000",
+                        "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["torch_distributed"] == {"backend": "nccl", "world_size": 1} and d["value"] > 0
+    e = d["end_to_end"]
+    assert "error" not in e, e
+    assert e["assemble_gpus2_wall_s"] > 0 and e["assemble_gpus1_wall_s"] > 0
+    assert e["outputs_identical_to_the_single_gpu_run"] is True and "contig.fa" in e["output_md5"]
+
