@@ -38,6 +38,7 @@ extern "C" {
 #define PB_ENOMEM       -3   /* device or host allocation failed                            */
 #define PB_ERANGE       -4   /* k out of range (1..160), read too long (>= 500000, common.cpp:28) */
 #define PB_ENODEVICE    -5   /* no gfx950 device visible                                    */
+#define PB_EPEER        -6   /* N ranks: another rank has failed or died; the group was stopped (pb_dist_*) */
 
 #define PB_MAX_K        160  /* KmerN<Binstr159>, assemble.cpp:182                          */
 #define PB_OCC_BINS     65535 /* occurrenceDistribution.resize(UINT16_MAX), counter.h:335   */
@@ -58,6 +59,7 @@ const char *pb_last_error(const pb_ctx *ctx);          /* ctx may be NULL: error
  *   "merge_table" / "merge_16b"  1 = owner-side merge through the global table / with 16-byte records
  *   "chain_rank_full" 1 = pointer jumping over all chain states;  "grid_cap" n = cap on the grid of the direct counting kernel
  *   "verbose"         1 = one line per super-k-mer pass attempt on stderr (bucket bits, records, flagged buckets, spilled records) */
+int         pb_check_option(const char *name, long value);   /* PB_OK if pb_set_option would take it (no context, no GPU: launchers check before they fork) */
 int         pb_set_option(pb_ctx *ctx, const char *name, long value);
 /* name, CU count, HBM bytes of the context's device (for reports; not in the reference) */
 int         pb_device_info(const pb_ctx *ctx, char *name, size_t name_cap, int *n_cu, uint64_t *hbm_bytes);
@@ -148,6 +150,22 @@ int pb_sk_count_records(pb_ctx *ctx, unsigned k, const void *dev_records, uint64
  *   pb_dist_count_considering_contigs  pb_count_considering_contigs over all ranks' surviving reads (the contig table is replicated)
  *   pb_dist_allreduce_u64  element-wise sum of a host array (read-length histogram, kept-read counts) */
 int pb_dist_shared_create(int world, void **shared);
+/* Launcher side of an N-rank run (no HIP call in any of these; no reference counterpart: the reference is one process).
+ *   pb_dist_launch         forks world - 1 ranks BEFORE the process has touched the GPU and returns in every process with its rank;
+ *                          children die with the launcher (PR_SET_PDEATHSIG), the launcher gets a thread that reaps them and stops
+ *                          the group (every barrier returns PB_EPEER) as soon as one ends abnormally
+ *   pb_dist_mark_failed    async-signal-safe: stops the group (a rank's crash handler calls it before re-raising the signal)
+ *   pb_dist_report_failure a rank that cannot go on: its exit status and the one line for stderr; stops the group
+ *   pb_dist_finish         launcher, after its own run: waits for the ranks (kills what does not leave a failed group within 10 s) and
+ *                          returns the run's exit status and its ONE error message (own failure, else the first rank's own reason,
+ *                          else "rank r was killed by signal s")
+ *   pb_dist_shared_barrier the group's barrier without a context (tests) */
+int  pb_dist_launch(void *shared, int *rank);
+void pb_dist_mark_failed(void *shared);
+int  pb_dist_failed(void *shared);
+int  pb_dist_report_failure(void *shared, int rank, int code, const char *msg, int secondary);
+int  pb_dist_finish(void *shared, int own_code, const char *own_msg, int own_secondary, int *exit_code, char *msg, size_t msg_cap);
+int  pb_dist_shared_barrier(void *shared, int rank);
 int pb_dist_attach(pb_ctx *ctx, void *shared, int rank, int world, int use_rccl);
 int pb_dist_detach(pb_ctx *ctx);
 int pb_dist_info(const pb_ctx *ctx, int *rank, int *world, int *rccl);

@@ -316,20 +316,34 @@ void pb_destroy(pb_ctx *ctx)
 
 const char *pb_last_error(const pb_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
+// which field of the context an option sets; nullptr: unknown name or value out of range
+static int *option_slot(pb_ctx *ctx, const std::string &n, long value)
+{
+    if (n == "count_path" && value >= 0 && value <= 2) return &ctx->opt_count_path;
+    if (n == "sk_bucket_bits" && (value == 0 || (value >= 2 && value <= SK_MAX_B))) return &ctx->sk_force_bits;
+    if (n == "sk_l1_bits" && value >= 0 && value <= 9) return &ctx->sk_force_l1;
+    if (n == "merge_table" && (value == 0 || value == 1)) return &ctx->opt_merge_table;
+    if (n == "merge_16b" && (value == 0 || value == 1)) return &ctx->opt_merge_16b;
+    if (n == "chain_rank_full" && (value == 0 || value == 1)) return &ctx->opt_chain_rank_full;
+    if (n == "verbose" && (value == 0 || value == 1)) return &ctx->opt_verbose;
+    if (n == "dist_design" && (value == 0 || value == 1)) return &ctx->opt_dist_design;
+    if (n == "grid_cap" && value >= 0 && value <= (1 << 20)) return &ctx->opt_grid_cap;
+    return nullptr;
+}
+
+int pb_check_option(const char *name, long value)
+{
+    if (!name) return PB_EINVAL;
+    pb_ctx probe;                               // (plain fields only: no device is touched)
+    return option_slot(&probe, name, value) ? PB_OK : PB_EINVAL;
+}
+
 int pb_set_option(pb_ctx *ctx, const char *name, long value)
 {
     if (!ctx || !name) return PB_EINVAL;
-    const std::string n(name);
-    if (n == "count_path" && value >= 0 && value <= 2) ctx->opt_count_path = (int)value;
-    else if (n == "sk_bucket_bits" && (value == 0 || (value >= 2 && value <= SK_MAX_B))) ctx->sk_force_bits = (int)value;
-    else if (n == "sk_l1_bits" && value >= 0 && value <= 9) ctx->sk_force_l1 = (int)value;
-    else if (n == "merge_table" && (value == 0 || value == 1)) ctx->opt_merge_table = (int)value;
-    else if (n == "merge_16b" && (value == 0 || value == 1)) ctx->opt_merge_16b = (int)value;
-    else if (n == "chain_rank_full" && (value == 0 || value == 1)) ctx->opt_chain_rank_full = (int)value;
-    else if (n == "verbose" && (value == 0 || value == 1)) ctx->opt_verbose = (int)value;
-    else if (n == "dist_design" && (value == 0 || value == 1)) ctx->opt_dist_design = (int)value;
-    else if (n == "grid_cap" && value >= 0 && value <= (1 << 20)) ctx->opt_grid_cap = (int)value;
-    else { ctx->err = "pb_set_option: unknown option or value out of range: " + n; return PB_EINVAL; }
+    int *slot = option_slot(ctx, name, value);
+    if (!slot) { ctx->err = std::string("pb_set_option: unknown option or value out of range: ") + name; return PB_EINVAL; }
+    *slot = (int)value;
     return PB_OK;
 }
 

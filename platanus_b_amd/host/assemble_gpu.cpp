@@ -5,7 +5,8 @@
 // Counter / BruijnGraph call whose cost is per k-mer or per read window is a C-ABI call into the HIP library, the
 // ~10^4-node cleaning steps stay on the host (node_graph.hpp).  No CPU fallback: without the device the constructor fails.
 #include "assemble_gpu.hpp"
-#include "device_graph.hpp"
+#include "device_handover.hpp"
+#include <memory>
 #include "schedule.hpp"
 #include "read_files.hpp"
 
@@ -134,27 +135,12 @@ struct Driver {
         g.set_k(kk);
         if (!getenv("PB_GRAPH_FETCH")) {
             // compact hand-over: adjacency and chain arrays stay on the device, only the nodes the DFS can land on come back
-            NodeSet<W> nd;
-            ChainRecords cr;
-            nd.k = kk;
-            {
-                Tick t("adjacency (device)");
-                log("connecting kmers...");
-                chk(pb_graph_adjacency(ctx, nullptr, nullptr));
-            }
-            {
-                Tick t("chain compaction + node export (device + D2H)");
-                u64 nc = 0, words = 0, nn = 0;
-                chk(pb_graph_chains(ctx, &nc, &words));
-                chk(pb_graph_nodes(ctx, &nn));
-                cr.len.resize(nc); cr.end_a.resize(nc); cr.end_b.resize(nc); cr.root.resize(nc); cr.sum.resize(nc); cr.seq_woff.resize(nc); cr.seq.resize(words);
-                chk(pb_graph_fetch_chain_records(ctx, cr.len.data(), cr.sum.data(), cr.end_a.data(), cr.end_b.data(), cr.root.data(), cr.seq_woff.data(),
-                                                 cr.seq.data()));
-                nd.idx.resize(nn); nd.meta.resize(nn); nd.chain.resize(nn); nd.nbr.resize(2 * nn); nd.nb8.resize(8 * nn); nd.keys.resize(nn * W);
-                chk(pb_graph_fetch_nodes(ctx, nd.idx.data(), nd.meta.data(), nd.chain.data(), nd.nbr.data(), nd.nb8.data(), nd.keys.data()));
-            }
-            Tick t("DFS replay, chain level (host)");
-            make_initial_from_nodes(g, nd, cr);
+            std::unique_ptr<Tick> t;
+            graph_from_device<W>(ctx, g, kk, [this](int rc) { chk(rc); }, [&](const char *stage) {
+                if (!strncmp(stage, "adjacency", 9)) log("connecting kmers...");
+                t.reset();
+                t.reset(new Tick(stage));
+            });
             return;
         }
         // development / A-B: the full per-k-mer arrays on the host (PB_GRAPH_FETCH=full, PB_NO_CHAINS=1 for the k-mer-level replay)

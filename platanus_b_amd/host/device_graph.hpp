@@ -11,6 +11,8 @@
 #include "node_graph.hpp"
 #include <algorithm>
 #include <cstdint>
+#include <stdexcept>
+#include <string>
 #include <vector>
 
 namespace pbh {
@@ -346,6 +348,11 @@ void make_initial_from_chains(Graph<W> &gr, const DeviceGraphInput<W> &in, const
 // of the nodes with the chains' smallest members (root[c]): an interior k-mer of a chain is only ever a root through that.
 namespace pbh {
 
+[[noreturn]] inline void handover_fail(const std::string &what)
+{
+    throw std::runtime_error("device graph hand-over is inconsistent: " + what);
+}
+
 template <int W>
 struct NodeSet {
     unsigned k = 0;
@@ -370,7 +377,13 @@ struct NodeSet {
         }
         idx.swap(i2); meta.swap(m2); chain.swap(c2); nbr.swap(n2); nb8.swap(b2); keys.swap(k2);
     }
-    u64 slot_of(u64 i) const { return (u64)(std::lower_bound(idx.begin(), idx.end(), (uint32_t)i) - idx.begin()); }   // i is a node by construction
+    // i is a node by construction; a value from the device that is none ends the run with a message instead of an out-of-range access
+    u64 slot_of(u64 i) const
+    {
+        const u64 s = (u64)(std::lower_bound(idx.begin(), idx.end(), (uint32_t)i) - idx.begin());
+        if (s >= idx.size() || idx[s] != i) handover_fail("k-mer index " + std::to_string(i) + " is not among the " + std::to_string(idx.size()) + " exported nodes");
+        return s;
+    }
     unsigned adj(u64 s) const { return meta[s] & 0xFFu; }
     unsigned orient(u64 s) const { return (meta[s] >> 8) & 1u; }
     unsigned count(u64 s) const { return meta[s] >> 16; }
@@ -413,6 +426,19 @@ void make_initial_from_nodes(Graph<W> &gr, NodeSet<W> &nd, const ChainRecords &c
     gr.right.clear();
     nd.sort();
     const u64 nn = nd.size(), nc = cs.size();
+    // everything the replay indexes with comes from the device: checked once here (chain ids, sequence ranges, node order) and in
+    // slot_of (k-mer indices), so that a wrong word becomes "Error: ..." with the offending record, never a wild host access
+    for (u64 s = 0; s < nn; ++s) {
+        if (s && nd.idx[s] <= nd.idx[s - 1]) handover_fail("node " + std::to_string(s) + " repeats k-mer index " + std::to_string(nd.idx[s]));
+        if (nd.chain[s] < CHAIN_COMPLEX && nd.chain[s] >= nc)
+            handover_fail("node " + std::to_string(s) + " (k-mer " + std::to_string(nd.idx[s]) + ") names chain " + std::to_string(nd.chain[s]) + " of " + std::to_string(nc));
+    }
+    for (u64 c = 0; c < nc; ++c) {
+        const u64 nw = ((u64)cs.len[c] + k - 1 + 31) / 32;
+        if (cs.len[c] == 0 || cs.seq_woff[c] > cs.seq.size() || nw > cs.seq.size() - cs.seq_woff[c])
+            handover_fail("chain " + std::to_string(c) + ": length " + std::to_string(cs.len[c]) + ", sequence words [" + std::to_string(cs.seq_woff[c]) + ", +" +
+                          std::to_string(nw) + ") of " + std::to_string(cs.seq.size()));
+    }
     std::vector<uint8_t> visited(nn, 0), chain_done(nc, 0);
     std::vector<uint32_t> by_root(nc);
     for (u64 c = 0; c < nc; ++c) by_root[c] = (uint32_t)c;

@@ -137,8 +137,11 @@ static int main_kmer_divide(int argc, char **argv)       // options: kmer_divide
     }
 }
 
-// A crash says where: the frames go to stderr (async-signal-safe calls only), then the default action takes over, so the exit status
-// is still the signal's (the reference has no such handler; its crashes are bare).
+// A crash says where: the frames go to stderr (async-signal-safe calls only), the other ranks of an N-rank run are released from their
+// barriers (pb_dist_mark_failed: an atomic store and a futex wake), then the default action takes over, so the exit status is still the
+// signal's (the reference has no such handler; its crashes are bare).  The handler runs on a stack of its own, so that a stack
+// overflow leaves its frames too.
+static void *g_shared = nullptr;
 static void crash_trace(int sig)
 {
     static const char msg[] = "\nplatanus_b: fatal signal, frames:\n";
@@ -146,20 +149,32 @@ static void crash_trace(int sig)
     void *frames[48];
     const int n = backtrace(frames, 48);
     backtrace_symbols_fd(frames, n, 2);
+    if (g_shared) pb_dist_mark_failed(g_shared);
     signal(sig, SIG_DFL);
     raise(sig);
 }
 
+static void install_crash_trace()
+{
+    void *warm[4];
+    (void)backtrace(warm, 4);                         // (loads libgcc's unwinder now, not inside the handler)
+    static char alt[1 << 16];
+    stack_t ss;
+    ss.ss_sp = alt;
+    ss.ss_size = sizeof(alt);
+    ss.ss_flags = 0;
+    sigaltstack(&ss, nullptr);
+    struct sigaction sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.sa_handler = crash_trace;
+    sa.sa_flags = SA_ONSTACK | SA_NODEFER;
+    sigemptyset(&sa.sa_mask);
+    for (int sig : {SIGSEGV, SIGBUS, SIGFPE, SIGILL, SIGABRT}) sigaction(sig, &sa, nullptr);
+}
+
 int main(int argc, char **argv)
 {
-    {
-        void *warm[4];
-        (void)backtrace(warm, 4);                     // (loads libgcc's unwinder now, not inside the handler)
-        signal(SIGSEGV, crash_trace);
-        signal(SIGBUS, crash_trace);
-        signal(SIGFPE, crash_trace);
-        signal(SIGILL, crash_trace);
-    }
+    install_crash_trace();
     show_version_and_args(argc, argv);
     if (argc >= 2 && strcmp(argv[1], "-v") == 0) return 0;                       // main.cpp:77-79
     if (argc >= 2 && strcmp(argv[1], "kmer_divide") == 0) return main_kmer_divide(argc, argv);
@@ -205,52 +220,56 @@ int main(int argc, char **argv)
     }
     if (o.files.empty()) { usage(); return 1; }
     if (n_ranks < 1 || n_ranks > 64 || (comm != "rccl" && comm != "host")) { usage(); return 1; }
-    // N ranks: the processes are forked HERE, before anything touches the GPU; what they share (barrier, headers, outboxes) is
-    // set up first so that every child inherits it
-    struct Ranks { pid_t pid[64]; } *ranks = nullptr;
+    // what needs no GPU is checked before any rank exists: the message comes once and the exit status is the reference's
+    for (const auto &nv : o.gpu_options)
+        if (pb_check_option(nv.first.c_str(), nv.second) != PB_OK) {
+            std::cerr << "Error: libpbgpu: pb_set_option: unknown option or value out of range: " << nv.first << std::endl;
+            return 2;
+        }
+    if (n_ranks > 1 && o.kmer_occ_only) {
+        std::cerr << "Error: -kmer_occ_only with -gpus > 1: the slot layout of PREFIX_kmer_occ.bin is defined by the order in which ONE process first sees "
+                     "every k-mer (counter.h:458-476 at -t 1); run it on one GPU" << std::endl;
+        return 2;
+    }
+    // N ranks: the processes are forked HERE (pb_dist_launch), before anything touches the GPU; what they share (barrier, headers,
+    // outboxes) is set up first so that every child inherits it.  A child dies with the launcher; the launcher watches the children.
+    void *shared = nullptr;
     if (n_ranks > 1) {
-        void *shared = nullptr;
         if (pb_dist_shared_create(n_ranks, &shared) != PB_OK) { std::cerr << "Error: cannot set up the shared memory of " << n_ranks << " ranks" << std::endl; return 2; }
-        ranks = (Ranks *)mmap(nullptr, sizeof(Ranks), PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
-        if (ranks == MAP_FAILED) { std::cerr << "Error: mmap" << std::endl; return 2; }
-        memset(ranks, 0, sizeof(Ranks));
-        ranks->pid[0] = getpid();
+        g_shared = shared;
         o.world = n_ranks;
         o.shared = shared;
         o.rccl = comm == "rccl" && !share_gpu;
-        fflush(nullptr);
-        for (int r = 1; r < n_ranks; ++r) {
-            const pid_t c = fork();
-            if (c < 0) { std::cerr << "Error: fork" << std::endl; for (int q = 1; q < r; ++q) kill(ranks->pid[q], SIGKILL); return 2; }
-            if (c == 0) { o.rank = r; o.verbose = false; break; }
-            ranks->pid[r] = c;
-        }
+        if (pb_dist_launch(shared, &o.rank) != PB_OK) { std::cerr << "Error: fork" << std::endl; return 2; }
+        if (o.rank) o.verbose = false;
         if (!share_gpu) o.device += o.rank;
     }
-    // a rank that fails takes the others with it (they would wait for it at the next collective forever)
-    auto fail_all = [&]() { if (ranks) for (int r = 0; r < n_ranks; ++r) if (r != o.rank && ranks->pid[r] > 0) kill(ranks->pid[r], SIGKILL); };
     int rc = 0;
+    std::string fail;                          // the line for stderr when this rank's run ends in an exception
     try {
         rc = pbh::run_assemble_gpu(o);
     } catch (const pbh::RefError &e) {           // the reference's exceptions: message, exit status = error id (main.cpp:118-127, common.h:97-100)
-        std::cerr << "Error(" << e.id << "): " << e.what() << std::endl;
-        fail_all();
-        if (o.rank) _exit(e.id ? e.id : 2);
-        return e.id;
+        fail = "Error(" + std::to_string(e.id) + "): " + e.what();
+        rc = e.id ? e.id : 2;
     } catch (const std::exception &e) {
-        std::cerr << "Error: " << e.what() << std::endl;
-        fail_all();
-        if (o.rank) _exit(2);
-        return 2;
+        fail = std::string("Error: ") + e.what();
+        rc = 2;
     }
-    if (o.rank) { fflush(nullptr); _exit(rc); }
-    if (ranks)
-        for (int r = 1; r < n_ranks; ++r) {
-            int st = 0;
-            if (waitpid(ranks->pid[r], &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) {
-                std::cerr << "Error: rank " << r << " did not finish" << std::endl;
-                if (rc == 0) rc = 2;
-            }
-        }
+    if (!shared) {
+        if (!fail.empty()) { std::cerr << fail << std::endl; return rc; }
+        return process_information(rc);
+    }
+    // N ranks.  A rank never signals another: a failing rank says why in the shared block and leaves; that stops the group (every
+    // barrier returns), the others leave with "a peer has failed", and the launcher prints ONE message and returns ONE status.
+    const bool secondary = fail.find("a peer rank has failed") != std::string::npos;
+    if (o.rank) {
+        if (!fail.empty()) pb_dist_report_failure(shared, o.rank, rc, fail.c_str(), secondary ? 1 : 0);
+        fflush(nullptr);
+        _exit(fail.empty() ? rc : (rc ? rc : 2));
+    }
+    int exit_code = 0;
+    char msg[1024];
+    pb_dist_finish(shared, fail.empty() ? 0 : rc, fail.c_str(), secondary ? 1 : 0, &exit_code, msg, sizeof(msg));
+    if (exit_code) { std::cerr << (msg[0] ? msg : "Error: a rank did not finish") << std::endl; return exit_code; }
     return process_information(rc);
 }

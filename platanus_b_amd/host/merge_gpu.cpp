@@ -1,6 +1,6 @@
 // `platanus_b merge` on the device path (merge.cpp:86-147).
 #include "merge.hpp"
-#include "device_graph.hpp"
+#include "device_handover.hpp"
 #include <iostream>
 
 extern "C" {
@@ -29,23 +29,8 @@ static void merge_run(pb_ctx *ctx, const MergeOptions &opt, const MergeContigs &
     chk(pb_count_considering_contigs(ctx, k, hist.data(), &max_occ, &nd));        // no reads resident: just the contig table
     if (verbose) std::cerr << "loading kmers..." << std::endl;
     chk(pb_retain(ctx, 0, &n));                                                    // sortedKeyFromKmerFile(0) + loadKmer(0, ...)
-    std::vector<u64> keys(n * W);
-    std::vector<u16> counts(n);
-    std::vector<uint8_t> adj(n), orient(n);
-    std::vector<uint32_t> nbr(2 * n), chain_of(n);
-    chk(pb_fetch_retained(ctx, keys.data(), counts.data()));
+    (void)n;
     if (verbose) std::cerr << "connecting kmers..." << std::endl;
-    chk(pb_graph_adjacency(ctx, adj.data(), nbr.data()));
-    u64 nc = 0, words = 0;
-    chk(pb_graph_chains(ctx, &nc, &words));
-    std::vector<uint32_t> ch_len(nc), ch_a(nc), ch_b(nc);
-    std::vector<u64> ch_sum(nc), ch_woff(nc), ch_seq(words);
-    chk(pb_graph_fetch_chains(ctx, chain_of.data(), orient.data(), ch_len.data(), ch_sum.data(), ch_a.data(), ch_b.data(), ch_woff.data(), ch_seq.data()));
-    DeviceGraphInput<W> in;
-    in.k = k; in.n = n; in.keys = keys.data(); in.counts = counts.data(); in.adj = adj.data(); in.nbr = nbr.data();
-    ChainSet cs;
-    cs.n_chains = nc; cs.chain_of = chain_of.data(); cs.orient = orient.data(); cs.len = ch_len.data(); cs.sum = ch_sum.data();
-    cs.end_a = ch_a.data(); cs.end_b = ch_b.data(); cs.seq_woff = ch_woff.data(); cs.seq = ch_seq.data();
     Graph<W> g;
     g.set_k(k);
     g.set_thresholds(atof(opt.bubble.c_str()), opt.branch);
@@ -60,7 +45,8 @@ static void merge_run(pb_ctx *ctx, const MergeOptions &opt, const MergeContigs &
         chk(pb_edit_distances(ctx, b, (const uint64_t *)offsets, n_pairs, (uint64_t *)dist_out));
         return true;
     };
-    make_initial_from_chains(g, in, cs);
+    // the same hand-over as `assemble` (device_handover.hpp): nodes + chain records, every device-produced index checked before use
+    graph_from_device<W>(ctx, g, k, chk);
     g.cut_branch_iterative(verbose);
     g.crush_bubble_iterative(avg_cov, verbose);
     std::vector<ContigRecord> contigs, junctions;

@@ -380,12 +380,14 @@ struct Graph {
             Straight *st = &its[i]->second;
             if (st->out >> 4) {
                 Junction *jn = find_junction(pred(its[i]->first, flag2base(st->out >> 4)));
+                if (!jn) throw std::runtime_error("cutBranch: the device marked a tip whose junction is not in the junction table");
                 jn->out ^= 1u << st->get(st->length - 1);
             } else {
                 K jk;
                 for (unsigned j = 1; j < k; ++j) jk.set(j, st->get(j - 1));
                 jk.set(0, flag2base(st->out & 0xf));
                 Junction *jn = find_junction(jk);
+                if (!jn) throw std::runtime_error("cutBranch: the device marked a tip whose junction is not in the junction table");
                 jn->out ^= 1u << (4 + st->get(k - 1));
             }
             delete_straight(*st);

@@ -134,7 +134,22 @@ def test_cli_n_ranks_refuses_kmer_occ_only(tmp_path):
     synth.write_pair_files(str(tmp_path / "in"), 5000, 20, 3)
     p = subprocess.run([BIN, "assemble", "-kmer_occ_only", "-gpus", "2", "-share_gpu", "-o", "out", "-f", "in_1.fq", "in_2.fq"], cwd=tmp_path, capture_output=True,
                        text=True, timeout=300)
-    assert p.returncode != 0 and "one GPU" in p.stderr
+    assert p.returncode == 2 and "one GPU" in p.stderr and sum(ln.startswith("Error") for ln in p.stderr.splitlines()) == 1
+
+
+def test_cli_n_ranks_error_every_rank_hits_is_said_once_with_the_reference_status(tmp_path):
+    """A missing input file is an error of every rank: ONE message, and the exit status of the one-rank run (round 2: the ranks killed
+    each other and the status depended on timing)."""
+    from platanus_b_amd import synth
+    synth.write_pair_files(str(tmp_path / "in"), 5000, 20, 3)
+    one = subprocess.run([BIN, "assemble", "-o", "out", "-f", "in_1.fq", "nowhere.fq"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert one.returncode not in (0, -9)
+    for _ in range(3):
+        p = subprocess.run([BIN, "assemble", "-gpus", "3", "-share_gpu", "-o", "out", "-f", "in_1.fq", "nowhere.fq"], cwd=tmp_path, capture_output=True, text=True,
+                           timeout=300)
+        assert p.returncode == one.returncode, (p.returncode, p.stderr[-600:])
+        errs = [ln for ln in p.stderr.splitlines() if ln.startswith("Error")]
+        assert errs == [ln for ln in one.stderr.splitlines() if ln.startswith("Error")], p.stderr[-600:]
 
 
 def test_cli_kmer_occ_only_byte_identical(manifest, tmp_path):
@@ -291,7 +306,7 @@ def test_cli_random_differential_against_oracle_cli():
     import sys
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_cli.py"), "12", "21"], capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
-    assert "12 cases, 0 mismatches" in p.stdout
+    assert "12 cases, 0 mismatches" in p.stdout and "SIGNAL" not in p.stdout          # (a run that dies of a signal is a failed case)
     if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "platanus_b")):
         assert "checker: reference" in p.stdout
 
@@ -303,4 +318,4 @@ def test_cli_kmer_divide_and_merge_random_options_against_oracle_cli():
     import sys
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_cli2.py"), "4", "11"], capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
-    assert "4 cases, 0 mismatches" in p.stdout
+    assert "4 cases, 0 mismatches" in p.stdout and "SIGNAL" not in p.stdout

@@ -18,6 +18,14 @@ ORC = os.path.join(ROOT, "oracle", "pb_oracle")
 REF = os.path.join(ROOT, "oracle", "_ref", "platanus_b")
 
 
+def keep_case(td, case, what="fuzz_cli"):
+    """A failed case leaves its inputs, command lines and outputs under gpurun_out/ (merged back from the GPU box)."""
+    import shutil
+    dst = os.path.join(ROOT, "gpurun_out", "failed_cases", f"{what}_{os.getpid()}_{case}")
+    shutil.copytree(td, dst, dirs_exist_ok=True)
+    print(f"  case kept in {dst}", flush=True)
+
+
 def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
@@ -73,6 +81,7 @@ def main():
             if rng.random() < 0.2:
                 args += ["-e", str(rng.choice(["20", "45"]))]
             outs = {}
+            signalled = False
             ranks = int(rng.choice([1, 1, 2, 3]))
             gpu_extra = ["-gpus", str(ranks), "-share_gpu"] if ranks > 1 else []
             # device code paths that these small inputs would not take by themselves (same results): the super-k-mer pass for k0 <= 32
@@ -89,14 +98,14 @@ def main():
                 os.mkdir(d)
                 cmd = [binary, "assemble", *args, *extra, "-o", "out", "-f", "../in_1.fq", "../in_2.fq"]
                 p = subprocess.run(cmd, cwd=d, capture_output=True, text=True, timeout=600)
-                if p.returncode < 0:                  # killed by a signal: reported and run once more (see tools/fuzz_cli2.py::run)
-                    print(f"  SIGNAL {-p.returncode} from {os.path.basename(binary)} {' '.join(cmd[1:])} -- running it once more; its stderr ended:\n    " +
-                          p.stderr[-1800:].replace("\n", "\n    "), flush=True)
-                    for fn in os.listdir(d):
-                        os.remove(os.path.join(d, fn))
-                    p = subprocess.run(cmd, cwd=d, capture_output=True, text=True, timeout=600)
+                if p.returncode < 0:                  # killed by a signal: a failed case, whichever binary it was; the evidence is kept
+                    signalled = True
+                    print(f"  SIGNAL {-p.returncode} from {os.path.basename(binary)} {' '.join(cmd[1:])}; its stderr ended:\n    " +
+                          p.stderr[-3000:].replace("\n", "\n    "), flush=True)
+                    with open(os.path.join(d, "argv_and_stderr.txt"), "w") as f:
+                        f.write(" ".join(cmd) + f"\nexit: signal {-p.returncode}\n" + p.stderr)
                 outs[name] = (p.returncode, d)
-            same = outs["orc"][0] == outs["gpu"][0]
+            same = outs["orc"][0] == outs["gpu"][0] and not signalled
             if same and outs["orc"][0] == 0:
                 for fn in sorted(os.listdir(outs["orc"][1])):
                     if not fn.startswith("out_"):
@@ -107,6 +116,7 @@ def main():
                         print(f"  differs: {fn}")
             if not same:
                 bad += 1
+                keep_case(td, case)
                 print(f"MISMATCH case {case}: G={G} cov={cov} err={err} RL={RL} args={' '.join(args)} rc={outs['orc'][0]}/{outs['gpu'][0]}", flush=True)
             else:
                 nct = sum(1 for l in open(os.path.join(outs["gpu"][1], "out_contig.fa")) if l.startswith(">")) if outs["gpu"][0] == 0 else -1

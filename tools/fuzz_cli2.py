@@ -17,15 +17,16 @@ ORC = os.path.join(ROOT, "oracle", "pb_oracle")
 REF = os.path.join(ROOT, "oracle", "_ref", "platanus_b")
 
 
+SIGNALLED = []
+
+
 def run(binary, args, cwd):
     r = subprocess.run([binary, *args], cwd=cwd, capture_output=True, text=True, timeout=600)
-    if r.returncode < 0:
-        # Killed by a signal.  Seen once in ~700 runs of the GPU `merge` (SIGSEGV, round 2), not reproducible: 320 repeats of the same
-        # command and an AddressSanitizer build of the host over the same cases were clean.  Reported loudly and run once more, so that
-        # what the comparison below judges is the program's output, not that event.
-        print(f"  SIGNAL {-r.returncode} from {os.path.basename(binary)} {' '.join(args)} -- running it once more; its stderr ended:\n    " +
-              r.stderr[-1800:].replace("\n", "\n    "), flush=True)
-        r = subprocess.run([binary, *args], cwd=cwd, capture_output=True, text=True, timeout=600)
+    if r.returncode < 0:              # killed by a signal: the case fails, whichever binary it was; the crash handler's frames are in stderr
+        SIGNALLED.append((binary, args))
+        print(f"  SIGNAL {-r.returncode} from {os.path.basename(binary)} {' '.join(args)}; its stderr ended:\n    " + r.stderr[-3000:].replace("\n", "\n    "), flush=True)
+        with open(os.path.join(cwd, "argv_and_stderr.txt"), "a") as f:
+            f.write(" ".join([binary, *args]) + f"\nexit: signal {-r.returncode}\n" + r.stderr + "\n")
     return r
 
 
@@ -46,6 +47,7 @@ def main():
             kd = [[], ["-mask"], ["-r", str(round(float(rng.uniform(0.05, 0.9)), 2))], ["-mask", "-R", str(round(float(rng.uniform(1.1, 3.0)), 2))]][int(rng.integers(0, 4))]
             mg = ["-k", str(round(float(rng.uniform(0.2, 1.0)), 2)), "-l", str(round(float(rng.uniform(0.5, 2.0)), 2)), "-u", str(rng.choice(["0", "1"])), "-m", "1"]
             ok = True
+            n_sig = len(SIGNALLED)
             for cmd, args, inputs in (("kmer_divide", kd, ["-k", "../occ_kmer_occ.bin", "-f", "../asm_contig.fa"]), ("merge", mg, ["-f", "../asm_contig.fa"])):
                 dirs = {}
                 for name, binary in (("orc", checker), ("gpu", GPU)):
@@ -73,8 +75,12 @@ def main():
                     if not os.path.exists(b) or not filecmp.cmp(os.path.join(dirs["orc"][1], fn), b, shallow=False):
                         ok = False
                         print(f"  {cmd}: {fn} differs")
+            if len(SIGNALLED) != n_sig:
+                ok = False
             if not ok:
                 bad += 1
+                from fuzz_cli import keep_case
+                keep_case(td, case, "fuzz_cli2")
                 print(f"MISMATCH case {case}: G={G} kmer_divide {' '.join(kd)} merge {' '.join(mg)}", flush=True)
             else:
                 print(f"case {case}: ok (G={G} kmer_divide {' '.join(kd)}; merge {' '.join(mg)})", flush=True)
