@@ -144,11 +144,11 @@ def replay_check(codes: np.ndarray, offsets: np.ndarray, k: int, min_occ: int) -
     return l.pbo_replay_check(codes.ctypes.data, offsets.ctypes.data, offsets.size - 1, k, min_occ, None, None)
 
 
-def parse_file_check(path: str, max_threads: int = 8):
-    """Product reader (platanus_b_amd/host/read_files.hpp, pieces in parallel) vs the oracle's sequential reader on one file.
-    Returns (code, n_reads, n_pieces); code 0 = identical reads."""
+def parse_file_check(path: str, max_threads: int = 8, parts: int = 1):
+    """Product reader (platanus_b_amd/host/read_files.hpp, pieces in parallel; parts > 1: the byte ranges of that many ranks, one after
+    the other) vs the oracle's sequential reader on one file.  Returns (code, n_reads, n_pieces); code 0 = identical reads."""
     l = lib()
-    l.pbo_parse_file_check.argtypes = [C.c_char_p, C.c_uint, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    l.pbo_parse_file_check_parts.argtypes = [C.c_char_p, C.c_uint, C.c_uint, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     nr, npc = C.c_uint64(), C.c_uint64()
-    rc = l.pbo_parse_file_check(path.encode(), max_threads, C.byref(nr), C.byref(npc))
+    rc = l.pbo_parse_file_check_parts(path.encode(), max_threads, parts, C.byref(nr), C.byref(npc))
     return rc, nr.value, npc.value

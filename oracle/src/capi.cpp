@@ -367,13 +367,18 @@ extern "C" int pbo_replay_check(const uint8_t *codes, const unsigned long long *
 #include "fastx.hpp"
 #include "../../platanus_b_amd/host/read_files.hpp"
 
-extern "C" int pbo_parse_file_check(const char *path, unsigned max_threads, unsigned long long *n_reads, unsigned long long *n_pieces)
+// parts > 1: the byte ranges of `parts` ranks (read_file's part / parts), concatenated in rank order, must be the sequential result too
+extern "C" int pbo_parse_file_check_parts(const char *path, unsigned max_threads, unsigned parts, unsigned long long *n_reads, unsigned long long *n_pieces)
 {
     try {
         pbo::ReadSet rs;
         pbo::read_fastx(path, rs);
         std::vector<pbh::ParsedPiece> pieces;
-        pbh::read_file(path, pieces, max_threads);
+        for (unsigned part = 0; part < std::max(parts, 1u); ++part) {
+            std::vector<pbh::ParsedPiece> mine;
+            pbh::read_file(path, mine, max_threads, part, std::max(parts, 1u));
+            for (auto &pc : mine) pieces.push_back(std::move(pc));
+        }
         static const unsigned char tab[16] = {46, 0, 46, 1, 3, 46, 46, 2, 46, 46, 46, 46, 46, 46, 4, 46};   // common.h:256, as the pack kernel applies it
         u64 r = 0;
         for (const pbh::ParsedPiece &pc : pieces) {
@@ -393,4 +398,9 @@ extern "C" int pbo_parse_file_check(const char *path, unsigned max_threads, unsi
         if (n_pieces) *n_pieces = pieces.size();
         return 0;
     } catch (...) { return -1; }
+}
+
+extern "C" int pbo_parse_file_check(const char *path, unsigned max_threads, unsigned long long *n_reads, unsigned long long *n_pieces)
+{
+    return pbo_parse_file_check_parts(path, max_threads, 1, n_reads, n_pieces);
 }

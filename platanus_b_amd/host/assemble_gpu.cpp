@@ -475,7 +475,7 @@ int run_assemble_gpu(const GpuAssembleOptions &opt)
             Tick t("read + parse files (host threads)");
             std::vector<std::thread> th;
             for (size_t i = base; i < hi_f; ++i)
-                th.emplace_back([&, i]() { try { read_file(opt.files[i], fpieces[i], per_file); } catch (...) { ferr[i] = std::current_exception(); } });
+                th.emplace_back([&, i]() { try { read_file(opt.files[i], fpieces[i], per_file, (unsigned)opt.rank, (unsigned)std::max(opt.world, 1)); } catch (...) { ferr[i] = std::current_exception(); } });
             for (auto &t2 : th) t2.join();
         }
         {
@@ -486,18 +486,16 @@ int run_assemble_gpu(const GpuAssembleOptions &opt)
             Tick t("device allocation for the read stream");
             u64 tb = 0, tr = 0;
             for (size_t i = base; i < hi_f; ++i) for (const ParsedPiece &pc : fpieces[i]) { tb += pc.bases.size(); tr += pc.off.size() - 1; }
-            if (opt.world > 1) { tb = tb / (u64)opt.world + (1u << 20); tr = tr / (u64)opt.world + 1024; }     // this rank's share
             d.chk(pb_reads_reserve(d.ctx, tb, tr));
         }
         for (size_t i = base; i < hi_f; ++i) {
             if (ferr[i]) std::rethrow_exception(ferr[i]);
             Tick t("upload + pack reads (H2D + device)");
-            // N ranks: rank r takes reads [r n / N, (r + 1) n / N) of every file (n = the file's reads).  The table that comes out
-            // of the merge does not depend on the partition (counts are sums), so any partition gives the reference's files.
+            // N ranks: rank r parsed its byte range of every file (read_file cuts at record marks) and takes all of it.  The table that
+            // comes out of the merge does not depend on the partition (counts are sums), so any partition gives the reference's files.
             u64 n_file = 0, seen = 0;
             for (const ParsedPiece &pc : fpieces[i]) n_file += pc.off.size() - 1;
-            const u64 take_lo = opt.world > 1 ? n_file * (u64)opt.rank / (u64)opt.world : 0;
-            const u64 take_hi = opt.world > 1 ? n_file * (u64)(opt.rank + 1) / (u64)opt.world : n_file;
+            const u64 take_lo = 0, take_hi = n_file;
             for (ParsedPiece &pc : fpieces[i]) {
                 const std::vector<u64> &off = pc.off;
                 const u64 n_piece = off.size() - 1;

@@ -38,8 +38,8 @@ static void usage()
               << "    -tmp DIR             : directory for temporary files (accepted, unused: no temporary files)\n"
               << "    -kmer_occ_only       : only output k-mer occurrence table (out_kmer_occ.bin; default off) \n"
               << "    -gpu INT             : device id (default 0; with -gpus N: rank r runs on device INT + r)\n"
-              << "    -gpus INT            : number of GPUs = processes (default 1): the reads are range-partitioned over them, the k-mer tables are\n"
-              << "                           merged by key owner over RCCL before every graph stage; same output files\n"
+              << "    -gpus INT            : number of GPUs = processes (default 1): every rank parses its byte range of the read files; records / k-mer tables\n"
+              << "                           are exchanged by key owner and the retained sets gathered over RCCL before every graph stage; same output files\n"
               << "    -share_gpu           : with -gpus N: all ranks on device -gpu, records exchanged through shared host memory (tests)\n"
               << "    -comm STR            : with -gpus N: rccl (default) or host (shared host memory instead of RCCL)\n"
               << "    -gpu_opt NAME=INT    : pb_set_option of libpbgpu (selects device code paths; results do not change)\n"

@@ -92,7 +92,10 @@ inline bool check_file_format(const char *data, size_t size, bool &fastq)
     return false;
 }
 
-inline void read_file(const std::string &path, std::vector<ParsedPiece> &pieces, unsigned max_threads)
+// part / parts (N ranks on one run): the file is cut into `parts` byte ranges at record-mark lines -- the same rule as the thread
+// pieces below, so the concatenation of all parts' pieces is the sequential result -- and only range `part` is parsed.  Every rank
+// computes the same cuts from the same bytes; a compressed file is still decompressed by every rank (one serial stream).
+inline void read_file(const std::string &path, std::vector<ParsedPiece> &pieces, unsigned max_threads, unsigned part = 0, unsigned parts = 1)
 {
     // compression by content, as `file -bL` tells the reference (common.cpp:88-118), not by the name
     FILE *fp = fopen(path.c_str(), "rb");
@@ -155,27 +158,49 @@ inline void read_file(const std::string &path, std::vector<ParsedPiece> &pieces,
     const char mark = fastq ? '@' : '>';
     size_t piece_bytes = 8u << 20;
     if (const char *pb = getenv("PB_PARSE_PIECE_BYTES")) { const long v = atol(pb); if (v >= 64) piece_bytes = (size_t)v; }   // tests: tiny pieces
-    unsigned n = (unsigned)std::min<size_t>(std::max<unsigned>(max_threads, 1), size / piece_bytes + 1);
-    std::vector<size_t> cut{0};
-    for (unsigned i = 1; i < n; ++i) {
-        size_t pos = size / n * i;
-        if (pos <= cut.back()) continue;
-        while (true) {                            // next line start
+    auto next_mark_line = [&](size_t pos) -> size_t {       // first line start at or after pos (exclusive of pos's own line) that begins with the mark
+        while (true) {
             const char *nl = (const char *)memchr(data + pos, '\n', size - pos);
-            if (!nl) { pos = size; break; }
+            if (!nl) return size;
             pos = (size_t)(nl - data) + 1;
-            if (pos >= size || data[pos] == mark) break;
+            if (pos >= size || data[pos] == mark) return std::min(pos, size);
         }
-        if (pos < size && pos > cut.back()) cut.push_back(pos);
+    };
+    // this rank's byte range [lo, hi)
+    size_t lo = 0, hi = size;
+    bool owns_end = true;                         // the reference's unconditional trailing flush belongs to the last non-empty range
+    if (parts > 1) {
+        std::vector<size_t> rc{0};
+        for (unsigned i = 1; i < parts; ++i) {
+            size_t pos = size / parts * i;
+            pos = pos <= rc.back() ? rc.back() : next_mark_line(pos);
+            rc.push_back(std::max(pos, rc.back()));
+        }
+        rc.push_back(size);
+        lo = rc[part];
+        hi = rc[part + 1];
+        unsigned last_owner = 0;
+        for (unsigned r = 0; r < parts; ++r) if (rc[r] < size) last_owner = r;
+        owns_end = part == last_owner;
+        if (lo >= hi && !(owns_end && lo == 0)) { pieces.clear(); return; }
     }
-    cut.push_back(size);
+    const size_t span = hi - lo;
+    unsigned n = (unsigned)std::min<size_t>(std::max<unsigned>(max_threads, 1), span / piece_bytes + 1);
+    std::vector<size_t> cut{lo};
+    for (unsigned i = 1; i < n; ++i) {
+        size_t pos = lo + span / n * i;
+        if (pos <= cut.back()) continue;
+        pos = std::min(next_mark_line(pos), hi);
+        if (pos < hi && pos > cut.back()) cut.push_back(pos);
+    }
+    cut.push_back(hi);
     const size_t np = cut.size() - 1;
     pieces.assign(np, ParsedPiece());
     std::vector<std::exception_ptr> err(np);
     std::vector<std::thread> th;
     for (size_t i = 0; i < np; ++i)
         th.emplace_back([&, i]() {
-            try { parse_piece(data + cut[i], data + cut[i + 1], fastq, i == 0, i + 1 == np, pieces[i]); }
+            try { parse_piece(data + cut[i], data + cut[i + 1], fastq, cut[i] == 0, owns_end && i + 1 == np, pieces[i]); }
             catch (...) { err[i] = std::current_exception(); }
         });
     for (auto &t : th) t.join();

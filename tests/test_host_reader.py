@@ -53,3 +53,18 @@ def test_piecewise_reader_equals_sequential(kind, piece, tmp_path, oracle_built,
     assert n_reads > 2900
     if int(piece) < 100000:
         assert n_pieces > 1                    # really cut
+
+
+@pytest.mark.parametrize("parts", [2, 3, 8, 64])
+@pytest.mark.parametrize("kind", ["fastq", "fasta"])
+def test_rank_byte_ranges_concatenate_to_the_sequential_result(kind, parts, tmp_path, oracle_built, monkeypatch):
+    """`assemble -gpus N`: rank r parses byte range r of every file (cut at record marks, like the thread pieces).  The ranges of all
+    ranks, in rank order, must hold exactly the sequential reader's reads -- including the trailing read without a newline, which
+    belongs to the last non-empty range, and ranks whose range is empty (64 parts of a small file)."""
+    rng = np.random.default_rng(7)
+    path = str(tmp_path / ("in." + kind))
+    (_tricky_fastq if kind == "fastq" else _multiline_fasta)(path, rng, n=400 if parts == 64 else 3000)
+    monkeypatch.setenv("PB_PARSE_PIECE_BYTES", "4096")
+    rc, n_reads, n_pieces = oracle_built.parse_file_check(path, 4, parts)
+    assert rc == 0
+    assert n_reads > (380 if parts == 64 else 2900) and n_pieces >= min(parts, 8)
