@@ -331,6 +331,7 @@ def main():
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
+    replayed = (not exchanging) and g.kernel_ms("graph_replay") > 0      # the timed passes were replays of the captured pass (pb_set_option "graph")
     instances = g.n_instances if world == 1 else n_reads * (READ_LEN - K + 1)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -396,6 +397,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "kernel_ms": k_ms, "measured_d2d_copy_GBs": copy_gbs,
                          "algorithmic_bytes_per_launch": instances * BYTES_PER_INSTANCE,
+                         "launch": ("one hipGraph replay per pass (3 memsets, sk_part1, sk_part2, sk_bucket, scalars + histogram head copied out): kernel_ms = HIP events "
+                                    "around the replay on the library's stream; kernels_ms = the three kernels' event pairs of the kernel-by-kernel pass that was captured"
+                                    if replayed else "kernel by kernel: kernel_ms = sum of the kernels' HIP event pairs on the library's stream"),
                          "kernels_ms": {"part1": parts["part1"], "part2": parts["part2"], "bucket_count": parts["bucket"],
                                         "flagged_buckets": parts["seg_compact"], "table_init": float(np.mean(init_ms)),
                                         "table_to_arrays": parts["compact"], "hist": float(np.mean(hist_ms))}},

@@ -120,6 +120,13 @@ struct pb_ctx {
     CopyPool *copy_pool = nullptr;
     u64 *h_hist = nullptr;              // pinned; filled behind sk_bucket_kernel so that the pass needs one host synchronisation
     bool h_hist_valid = false;
+    // the k <= 32 counting pass as a captured graph (memsets, sk_part1, sk_part2, sk_bucket, scalars + histogram copy-out): replayed while
+    // nothing the launches depend on has changed (sk_graph_key: every pointer, size and launch dimension that went into the capture)
+    hipGraphExec_t sk_graph = nullptr;
+    std::vector<u64> sk_graph_key;
+    u64 *h_scalars = nullptr;           // pinned u64[16]: the pass scalars of a replay
+    u64 h_hist_hi = 65536;              // bins of h_hist at or beyond this are zero
+    int opt_graph = 1;                  // pb_set_option("graph"): 0 = every pass launched kernel by kernel (with per-kernel timers)
     u64 sk_owner_cap1 = 0;          // pb_sk_owner_records: records per owner region
     u64 exp_cur[64] = {0};           // start of every owner's segment in the export (pb_export_begin -> pb_export_copy)
     std::vector<u32> sk_owner_cur;   // pb_sk_owner_records: records per (owner, XCD) region
@@ -231,12 +238,13 @@ struct LazyTimer {
     pb_ctx *ctx;
     const char *name;
     int slot;
-    LazyTimer(pb_ctx *c, const char *n, int s) : ctx(c), name(n), slot(s)
+    bool live;
+    LazyTimer(pb_ctx *c, const char *n, int s, bool record = true) : ctx(c), name(n), slot(s), live(record)
     {
         for (int i = 2 * s; i < 2 * s + 2; ++i) if (!ctx->lazy_ev[i]) (void)hipEventCreate(&ctx->lazy_ev[i]);
-        (void)hipEventRecord(ctx->lazy_ev[2 * s], ctx->stream);
+        if (live) (void)hipEventRecord(ctx->lazy_ev[2 * s], ctx->stream);
     }
-    void stop() { (void)hipEventRecord(ctx->lazy_ev[2 * slot + 1], ctx->stream); }
+    void stop() { if (live) (void)hipEventRecord(ctx->lazy_ev[2 * slot + 1], ctx->stream); }
     void read()                                  // after the stream has been synchronised past stop()
     {
         float ms = 0;
@@ -253,6 +261,7 @@ static inline unsigned grid_for(u64 n, unsigned block, unsigned max_blocks = 256
     return (unsigned)g;
 }
 
+#define SK_HIST_HEAD 1024            /* histogram bins a replayed pass copies out with its scalars */
 #include "kernels_count.inc"
 #include "kernels_superk.inc"
 #include "kernels_superk2.inc"
@@ -304,7 +313,9 @@ void pb_destroy(pb_ctx *ctx)
     release(ctx->layout_work); release(ctx->layout_slots); release(ctx->layout_out); release(ctx->scan_sums); release(ctx->slot_blk);
     for (auto &s : ctx->scratch) release(s);
     delete ctx->copy_pool;
+    if (ctx->sk_graph) (void)hipGraphExecDestroy(ctx->sk_graph);
     if (ctx->h_hist) (void)hipHostFree(ctx->h_hist);
+    if (ctx->h_scalars) (void)hipHostFree(ctx->h_scalars);
     for (int b = 0; b < 2; ++b) if (ctx->bounce[b]) { (void)hipHostFree(ctx->bounce[b]); (void)hipEventDestroy(ctx->bounce_ev[b]); }
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
@@ -328,6 +339,7 @@ static int *option_slot(pb_ctx *ctx, const std::string &n, long value)
     if (n == "verbose" && (value == 0 || value == 1)) return &ctx->opt_verbose;
     if (n == "dist_design" && (value == 0 || value == 1)) return &ctx->opt_dist_design;
     if (n == "grid_cap" && value >= 0 && value <= (1 << 20)) return &ctx->opt_grid_cap;
+    if (n == "graph" && (value == 0 || value == 1)) return &ctx->opt_graph;
     return nullptr;
 }
 
@@ -668,42 +680,99 @@ static int count_superk(pb_ctx *ctx, unsigned k, bool *done, bool want_pos = fal
         p.scalars = (u64 *)ctx->d_scalars.p;
         if ((rc = ensure(ctx, ctx->d_hist, 65536 * 8)) != PB_OK) return rc;
         p.hist = (u64 *)ctx->d_hist.p;
-        HIPCHK(hipMemsetAsync(ctx->d_hist.p, 0, 65536 * 8, ctx->stream));
-        HIPCHK(hipMemsetAsync(ctx->d_scalars.p, 0, 16 * 8, ctx->stream));
-        HIPCHK(hipMemsetAsync(ctx->part_meta.p, 0, (nb1 * SK_CUR1_STRIDE + 2 * nb2) * 4, ctx->stream));
         ctx->stage_ms["table_init"] = 0.f;                         // (the fallback table is initialised only if a flagged bucket needs it, below)
-        u64 sc[9];
+        u64 sc[10];
         {
             // one host synchronisation for the three kernels (the flags are needed before anything else is decided)
-            LazyTimer t1(ctx, "part1", 0);
             const u64 n_tiles = (ctx->stream_len + SK1_OWN - 1) / SK1_OWN;
             const size_t dig_bytes = (size_t)3 * 4 * (1u << p.l1);
             const u64 nw64 = (ctx->stream_len + 63) / 64 + PB_STREAM_PAD_WORDS64;
             const unsigned g1 = grid_for(n_tiles, 1, 256 * 16);
-            if (want_pos) sk_part1_kernel<0, true><<<g1, SK1_THREADS, dig_bytes, ctx->stream>>>((const u64 *)ctx->packed.p, cur_mask(ctx), ctx->stream_len, nw64, p);
-            else if (k == 32) sk_part1_kernel<32, false><<<g1, SK1_THREADS, dig_bytes, ctx->stream>>>((const u64 *)ctx->packed.p, cur_mask(ctx), ctx->stream_len, nw64, p);
-            else if (k == 31) sk_part1_kernel<31, false><<<g1, SK1_THREADS, dig_bytes, ctx->stream>>>((const u64 *)ctx->packed.p, cur_mask(ctx), ctx->stream_len, nw64, p);   // (the usual odd k)
-            else sk_part1_kernel<0, false><<<g1, SK1_THREADS, dig_bytes, ctx->stream>>>((const u64 *)ctx->packed.p, cur_mask(ctx), ctx->stream_len, nw64, p);
-            t1.stop();
-            LazyTimer t2(ctx, "part2", 1);
             // a few blocks per sub-stream, each striding over its tiles (most of cap1 is head-room: one block per tile would be mostly empty blocks)
             const u64 exp_tiles = (u64)(est_rec / (double)nb1) / SK2Q_RCAP + 1;
             const unsigned blocks_per_sub = (unsigned)std::min<u64>(std::max<u64>(exp_tiles / 4, 1), 64);
-            if (want_pos) sk_part2_raw16_kernel<true><<<dim3(blocks_per_sub, (unsigned)nb1), SK_THREADS, 0, ctx->stream>>>(p);
-            else sk_part2_raw16_kernel<false><<<dim3(blocks_per_sub, (unsigned)nb1), SK_THREADS, 0, ctx->stream>>>(p);
-            t2.stop();
-            LazyTimer t3(ctx, "bucket", 2);
             const unsigned g3 = grid_for(nb2, 1, 256 * 16);
-            if (want_pos) sk_bucket_kernel<0, true><<<g3, SK_ROLL_THREADS, 0, ctx->stream>>>(p, (u64 *)ctx->dist_keys.p, (u32 *)ctx->dist_counts.p, out_cap, (u32 *)ctx->sk_first.p);
-            else if (k == 32) sk_bucket_kernel<32, false><<<g3, SK_ROLL_THREADS, 0, ctx->stream>>>(p, (u64 *)ctx->dist_keys.p, (u32 *)ctx->dist_counts.p, out_cap, nullptr);
-            else sk_bucket_kernel<0, false><<<g3, SK_ROLL_THREADS, 0, ctx->stream>>>(p, (u64 *)ctx->dist_keys.p, (u32 *)ctx->dist_counts.p, out_cap, nullptr);
-            t3.stop();
-            HIPCHK(hipGetLastError());
-            HIPCHK(hipMemcpyAsync(sc, ctx->d_scalars.p, 72, hipMemcpyDeviceToHost, ctx->stream));
+            const size_t meta_bytes = (nb1 * SK_CUR1_STRIDE + 2 * nb2) * 4;
+            const u64 *mask = cur_mask(ctx);
             if (!ctx->h_hist) HIPCHK(hipHostMalloc((void **)&ctx->h_hist, 65536 * 8, hipHostMallocDefault));
-            HIPCHK(hipMemcpyAsync(ctx->h_hist, ctx->d_hist.p, 65536 * 8, hipMemcpyDeviceToHost, ctx->stream));   // final unless buckets were flagged
-            HIPCHK(hipStreamSynchronize(ctx->stream));
-            t1.read(); t2.read(); t3.read();
+            if (!ctx->h_scalars) HIPCHK(hipHostMalloc((void **)&ctx->h_scalars, 16 * 8, hipHostMallocDefault));
+            // everything the pass enqueues, in order; `timed`: with the per-kernel event pairs (not inside a capture)
+            auto enqueue = [&](bool timed, u64 *sc_dst) -> hipError_t {
+                hipError_t e;
+                if ((e = hipMemsetAsync(ctx->d_hist.p, 0, 65536 * 8, ctx->stream)) != hipSuccess) return e;
+                if ((e = hipMemsetAsync(ctx->d_scalars.p, 0, 16 * 8, ctx->stream)) != hipSuccess) return e;
+                if ((e = hipMemsetAsync(ctx->part_meta.p, 0, meta_bytes, ctx->stream)) != hipSuccess) return e;
+                LazyTimer t1(ctx, "part1", 0, timed);
+                if (want_pos) sk_part1_kernel<0, true><<<g1, SK1_THREADS, dig_bytes, ctx->stream>>>((const u64 *)ctx->packed.p, mask, ctx->stream_len, nw64, p);
+                else if (k == 32) sk_part1_kernel<32, false><<<g1, SK1_THREADS, dig_bytes, ctx->stream>>>((const u64 *)ctx->packed.p, mask, ctx->stream_len, nw64, p);
+                else if (k == 31) sk_part1_kernel<31, false><<<g1, SK1_THREADS, dig_bytes, ctx->stream>>>((const u64 *)ctx->packed.p, mask, ctx->stream_len, nw64, p);   // (the usual odd k)
+                else sk_part1_kernel<0, false><<<g1, SK1_THREADS, dig_bytes, ctx->stream>>>((const u64 *)ctx->packed.p, mask, ctx->stream_len, nw64, p);
+                t1.stop();
+                LazyTimer t2(ctx, "part2", 1, timed);
+                if (want_pos) sk_part2_raw16_kernel<true><<<dim3(blocks_per_sub, (unsigned)nb1), SK_THREADS, 0, ctx->stream>>>(p);
+                else sk_part2_raw16_kernel<false><<<dim3(blocks_per_sub, (unsigned)nb1), SK_THREADS, 0, ctx->stream>>>(p);
+                t2.stop();
+                LazyTimer t3(ctx, "bucket", 2, timed);
+                if (want_pos) sk_bucket_kernel<0, true><<<g3, SK_ROLL_THREADS, 0, ctx->stream>>>(p, (u64 *)ctx->dist_keys.p, (u32 *)ctx->dist_counts.p, out_cap, (u32 *)ctx->sk_first.p);
+                else if (k == 32) sk_bucket_kernel<32, false><<<g3, SK_ROLL_THREADS, 0, ctx->stream>>>(p, (u64 *)ctx->dist_keys.p, (u32 *)ctx->dist_counts.p, out_cap, nullptr);
+                else sk_bucket_kernel<0, false><<<g3, SK_ROLL_THREADS, 0, ctx->stream>>>(p, (u64 *)ctx->dist_keys.p, (u32 *)ctx->dist_counts.p, out_cap, nullptr);
+                t3.stop();
+                if ((e = hipGetLastError()) != hipSuccess) return e;
+                if ((e = hipMemcpyAsync(sc_dst, ctx->d_scalars.p, 80, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) return e;
+                // the occurrence distribution (final unless buckets were flagged).  A replay takes only the head with it: sk_bucket_kernel tallies
+                // counts below SK_LHIST in LDS bins and says in scalars[9] how far the others reach; the tail follows only if there is one
+                return hipMemcpyAsync(ctx->h_hist, ctx->d_hist.p, (timed ? 65536 : SK_HIST_HEAD) * 8, hipMemcpyDeviceToHost, ctx->stream);
+            };
+            // what a captured pass depends on (kernel arguments are copied into the graph at capture)
+            std::vector<u64> key = {(u64)k, (u64)p.m, (u64)p.w, (u64)p.B, (u64)p.l1, (u64)p.l2, p.cap1, (u64)p.cap2, (u64)(uintptr_t)p.bucket1, (u64)p.nx, (u64)(uintptr_t)p.cursor1,
+                                    (u64)(uintptr_t)p.bucket2, (u64)(uintptr_t)p.cursor2, (u64)(uintptr_t)p.flag2, (u64)(uintptr_t)p.fallback.slots, p.fallback.mask,
+                                    (u64)(uintptr_t)p.spill, p.spill_cap, (u64)(uintptr_t)p.scalars, (u64)(uintptr_t)p.hist, (u64)(uintptr_t)ctx->packed.p, (u64)(uintptr_t)mask,
+                                    ctx->stream_len, nw64, (u64)g1, (u64)g3, (u64)blocks_per_sub, (u64)nb1, (u64)dig_bytes, (u64)meta_bytes, (u64)(uintptr_t)ctx->dist_keys.p,
+                                    (u64)(uintptr_t)ctx->dist_counts.p, out_cap, (u64)(uintptr_t)ctx->h_hist, (u64)(uintptr_t)ctx->h_scalars};
+            const bool want_graph = ctx->opt_graph && !want_pos && !ctx->opt_verbose;
+            ctx->stage_ms["graph_replay"] = 0.f;
+            if (want_graph && ctx->sk_graph && key == ctx->sk_graph_key) {
+                // the pass as it was captured: one launch; its duration (events around it) is the pass's kernel time -- the per-kernel
+                // entries keep the values of the kernel-by-kernel pass over the same buffers
+                HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+                HIPCHK(hipGraphLaunch(ctx->sk_graph, ctx->stream));
+                HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+                HIPCHK(hipStreamSynchronize(ctx->stream));
+                float ms = 0;
+                (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+                ctx->stage_ms["graph_replay"] = 1.f;
+                ctx->stage_ms["graph_ms"] = ms;
+                memcpy(sc, ctx->h_scalars, 80);
+                const u64 reach = sc[9] + 1;                          // bins [0, reach) may be non-zero (the LDS bins end at SK_LHIST <= SK_HIST_HEAD)
+                if (reach > SK_HIST_HEAD) {
+                    HIPCHK(hipMemcpyAsync(ctx->h_hist + SK_HIST_HEAD, (const u64 *)ctx->d_hist.p + SK_HIST_HEAD, (std::min<u64>(reach, 65536) - SK_HIST_HEAD) * 8, hipMemcpyDeviceToHost, ctx->stream));
+                    HIPCHK(hipStreamSynchronize(ctx->stream));
+                }
+                const u64 now_hi = std::max<u64>(std::min<u64>(reach, 65536), SK_HIST_HEAD);
+                if (ctx->h_hist_hi > now_hi) memset(ctx->h_hist + now_hi, 0, (ctx->h_hist_hi - now_hi) * 8);    // (what an earlier pass left beyond)
+                ctx->h_hist_hi = now_hi;
+            } else {
+                HIPCHK(enqueue(true, sc));
+                HIPCHK(hipStreamSynchronize(ctx->stream));
+                ctx->h_hist_hi = 65536;
+                for (int sl = 0; sl < 3; ++sl) { LazyTimer t(ctx, sl == 0 ? "part1" : sl == 1 ? "part2" : "bucket", sl, false); t.read(); }
+                ctx->stage_ms["graph_ms"] = 0.f;
+                if (want_graph) {                                     // the same sequence, captured for the next pass over these buffers
+                    if (ctx->sk_graph) { (void)hipGraphExecDestroy(ctx->sk_graph); ctx->sk_graph = nullptr; }
+                    ctx->sk_graph_key.clear();
+                    hipGraph_t gr = nullptr;
+                    hipError_t e = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed);
+                    if (e == hipSuccess) {
+                        const hipError_t e1 = enqueue(false, ctx->h_scalars);
+                        e = hipStreamEndCapture(ctx->stream, &gr);
+                        if (e == hipSuccess) e = e1;
+                    }
+                    if (e == hipSuccess) e = hipGraphInstantiate(&ctx->sk_graph, gr, nullptr, nullptr, 0);
+                    if (gr) (void)hipGraphDestroy(gr);
+                    if (e == hipSuccess) ctx->sk_graph_key = key;
+                    else { ctx->sk_graph = nullptr; (void)hipGetLastError(); }      // (no graph: the pass goes on kernel by kernel)
+                }
+            }
         }
         if (ctx->opt_verbose)
             fprintf(stderr, "[pbgpu] super-k-mer pass: k %u, 2^%u buckets (l1 %u), cap1 %llu cap2 %u: windows %llu, records %llu, distinct %llu, flagged buckets %llu, "
@@ -786,7 +855,10 @@ static int count_superk(pb_ctx *ctx, unsigned k, bool *done, bool want_pos = fal
         ctx->sk_fcap_for = windows;
         if (attempt == 11 || fcap > (1ull << 36)) { ctx->err = "fallback table overflow"; return PB_ENOMEM; }
     }
-    ctx->stage_ms["count"] = ctx->stage_ms["part1"] + ctx->stage_ms["part2"] + ctx->stage_ms["bucket"] + ctx->stage_ms["seg_compact"];
+    // kernel time of the pass: the three kernels' event pairs, or -- a replayed graph -- the events around its one launch (the memsets, the
+    // two boundaries between the kernels and the copy-out are then inside: what the stream was busy for)
+    ctx->stage_ms["count"] = (ctx->stage_ms["graph_replay"] > 0.f ? ctx->stage_ms["graph_ms"] : ctx->stage_ms["part1"] + ctx->stage_ms["part2"] + ctx->stage_ms["bucket"]) +
+                             ctx->stage_ms["seg_compact"];
     ctx->stage_ms["compact"] = 0.f;
     if (ctx->sk_flagged + ctx->sk_spilled > 0) {                    // otherwise nothing went into the global table
         if ((rc = table_to_arrays<1>(ctx, ctx->table_cap, true)) != PB_OK) return rc;

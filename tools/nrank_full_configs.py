@@ -1,4 +1,4 @@
-"""BASELINE configs[3] / configs[4] as configs: `platanus_b assemble -gpus N` on the FULL read set (5 Mbp x 1000x, or 100 Mbp x 100x with
+"""BASELINE configs[3] / configs[4] as configs: `platanus_b assemble -gpus N` (N = 4 and 6: this pool admits at most 6 processes on a box's GPU, so 8 ranks cannot share it) on the FULL read set (5 Mbp x 1000x, or 100 Mbp x 100x with
 -m 256) against `assemble -gpus 1` on the same FASTQ files -- every output file compared byte for byte -- on ONE GPU that the N ranks share
 (-share_gpu: records and tables through shared host memory; the driver's 8-GPU node runs the RCCL path).  Both designs of the k0
 counting step (dist_design 0: run records exchanged before counting; 1: count, exchange (key,count), owner-side merge).
@@ -66,7 +66,8 @@ def run(tag, args, files, td):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", type=int, choices=[3, 4], required=True)
-    ap.add_argument("--ranks", type=int, default=8)
+    ap.add_argument("--ranks", type=int, default=4, help="ranks of the two N-rank runs (a one-GPU box of this pool admits at most 6 processes on its GPU)")
+    ap.add_argument("--ranks2", type=int, default=6, help="ranks of a third run (not a power of two: counted per rank, (key,count) tables merged); 0 = none")
     ap.add_argument("--workers", type=int, default=16)
     ap.add_argument("--scale", type=float, default=1.0, help="fraction of the coverage (development: small runs of the same script)")
     ap.add_argument("--out", default=None)
@@ -75,7 +76,7 @@ def main():
     cov = c["cov"] * a.scale
     n_pairs = int(c["genome"] * cov) // 300
     res = {"config": c["name"] + ("" if a.scale == 1.0 else f" (coverage x {a.scale})"), "genome_bp": c["genome"], "coverage": cov, "read_pairs": n_pairs, "seed": c["seed"],
-           "ranks": a.ranks, "placement": "all ranks on one MI355X (-share_gpu), exchange through shared host memory"}
+           "ranks": a.ranks, "ranks_third_run": a.ranks2, "placement": "all ranks on one MI355X (-share_gpu), exchange through shared host memory"}
     with tempfile.TemporaryDirectory(prefix="pb_cfg_", dir=os.environ.get("PB_BIG_TMP")) as td:
         parts = a.workers
         t0 = time.perf_counter()
@@ -86,14 +87,18 @@ def main():
         res["fastq"] = {"files": len(files), "bytes": sum(os.path.getsize(f) for f in files), "written_in_s": time.perf_counter() - t0}
         print("reads written:", res["fastq"], flush=True)
         res["runs"] = {}
-        for tag, args in (("g1", []), ("n_records", ["-gpus", str(a.ranks), "-share_gpu"]), ("n_counts", ["-gpus", str(a.ranks), "-share_gpu", "-gpu_opt", "dist_design=1"])):
+        plan = [("g1", []), ("n_records", ["-gpus", str(a.ranks), "-share_gpu"]), ("n_counts", ["-gpus", str(a.ranks), "-share_gpu", "-gpu_opt", "dist_design=1"])]
+        if a.ranks2:
+            plan.append(("n2_counts", ["-gpus", str(a.ranks2), "-share_gpu"]))
+        for tag, args in plan:
             res["runs"][tag] = run(tag, [*c["extra"], *args], files, td)
             print(tag, "exit", res["runs"][tag]["exit_status"], "wall", round(res["runs"][tag]["wall_s"], 2), flush=True)
         ref = res["runs"]["g1"]["outputs"]
-        for tag in ("n_records", "n_counts"):
+        nr = [t for t, _ in plan if t != "g1"]
+        for tag in nr:
             r = res["runs"][tag]
             r["outputs_identical_to_the_1_gpu_run"] = r["exit_status"] == 0 and bool(ref) and r["outputs"] == ref
-        res["all_identical"] = all(res["runs"][t].get("outputs_identical_to_the_1_gpu_run") for t in ("n_records", "n_counts")) and res["runs"]["g1"]["exit_status"] == 0
+        res["all_identical"] = all(res["runs"][t].get("outputs_identical_to_the_1_gpu_run") for t in nr) and res["runs"]["g1"]["exit_status"] == 0
     s = json.dumps(res, indent=1)
     if a.out:
         os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
