@@ -127,6 +127,7 @@ struct pb_ctx {
     u64 *h_scalars = nullptr;           // pinned u64[16]: the pass scalars of a replay
     u64 h_hist_hi = 65536;              // bins of h_hist at or beyond this are zero
     int opt_graph = 1;                  // pb_set_option("graph"): 0 = every pass launched kernel by kernel (with per-kernel timers)
+    int opt_bucket_form = 2;            // pb_set_option("sk_bucket_form"): 1 = sk_bucket_kernel (chunks of 768 records, per-wave piece lists), 2 = sk_bucket2_kernel (whole bucket)
     u64 sk_owner_cap1 = 0;          // pb_sk_owner_records: records per owner region
     u64 exp_cur[64] = {0};           // start of every owner's segment in the export (pb_export_begin -> pb_export_copy)
     std::vector<u32> sk_owner_cur;   // pb_sk_owner_records: records per (owner, XCD) region
@@ -135,6 +136,7 @@ struct pb_ctx {
     u64 sk_records = 0;            // super-k-mer records of the last counting pass (0 = other path)
     u64 sk_flagged = 0, sk_spilled = 0, sk_extra_for = 0;
     u64 sk_fcap = 0, sk_fcap_for = 0;   // capacity of the fallback table that an earlier pass over the same stream needed
+    u64 sk_room6_for = 0;               // ... and the stream (by its window count) whose buckets needed 6 x the mean as capacity
     u64 hist_done = 0;              // leading records of the distinct arrays already tallied into d_hist
     unsigned sk_bits = 0, sk_extra_bits = 0;       // bucket bits used; extra bits that an earlier pass over the same stream needed
     // pb_set_option: choices between equivalent implementations (tests and A/B runs; no option changes a result)
@@ -340,6 +342,7 @@ static int *option_slot(pb_ctx *ctx, const std::string &n, long value)
     if (n == "dist_design" && (value == 0 || value == 1)) return &ctx->opt_dist_design;
     if (n == "grid_cap" && value >= 0 && value <= (1 << 20)) return &ctx->opt_grid_cap;
     if (n == "graph" && (value == 0 || value == 1)) return &ctx->opt_graph;
+    if (n == "sk_bucket_form" && (value == 1 || value == 2)) return &ctx->opt_bucket_form;
     return nullptr;
 }
 
@@ -638,8 +641,9 @@ static int count_superk(pb_ctx *ctx, unsigned k, bool *done, bool want_pos = fal
     bool forced_b = false;
     if (ctx->sk_force_bits >= 2 && ctx->sk_force_bits <= SK_MAX_B) { B = (unsigned)ctx->sk_force_bits; forced_b = true; }
     u64 fcap = ctx->sk_fcap && ctx->sk_fcap_for == windows ? ctx->sk_fcap : 1ull << 20;
-    double room2 = ctx->sk_fcap && ctx->sk_fcap_for == windows ? 6.0 : 3.0;      // final-bucket capacity over the mean
+    double room2 = ctx->sk_room6_for && ctx->sk_room6_for == windows ? 6.0 : 3.0;      // final-bucket capacity over the mean
     for (int attempt = 0; attempt < 12; ++attempt) {
+        const auto t_attempt = std::chrono::steady_clock::now();
         p.B = B;
         p.l1 = std::max(B / 2, B > 9 ? B - 9 : 0u);                  // (a level has at most 2^9 digits in sk_part2; sk_part1 takes up to 2^11)
         if (ctx->sk_force_l1 >= 1 && ctx->sk_force_l1 < (int)B && (int)B - ctx->sk_force_l1 <= 9) p.l1 = (unsigned)ctx->sk_force_l1;
@@ -680,6 +684,7 @@ static int count_superk(pb_ctx *ctx, unsigned k, bool *done, bool want_pos = fal
         p.scalars = (u64 *)ctx->d_scalars.p;
         if ((rc = ensure(ctx, ctx->d_hist, 65536 * 8)) != PB_OK) return rc;
         p.hist = (u64 *)ctx->d_hist.p;
+        const double alloc_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_attempt).count();
         ctx->stage_ms["table_init"] = 0.f;                         // (the fallback table is initialised only if a flagged bucket needs it, below)
         u64 sc[10];
         {
@@ -713,7 +718,12 @@ static int count_superk(pb_ctx *ctx, unsigned k, bool *done, bool want_pos = fal
                 else sk_part2_raw16_kernel<false><<<dim3(blocks_per_sub, (unsigned)nb1), SK_THREADS, 0, ctx->stream>>>(p);
                 t2.stop();
                 LazyTimer t3(ctx, "bucket", 2, timed);
-                if (want_pos) sk_bucket_kernel<0, true><<<g3, SK_ROLL_THREADS, 0, ctx->stream>>>(p, (u64 *)ctx->dist_keys.p, (u32 *)ctx->dist_counts.p, out_cap, (u32 *)ctx->sk_first.p);
+                if (ctx->opt_bucket_form == 2) {
+                    if (want_pos) sk_bucket2_kernel<0, true><<<g3, SK_ROLL_THREADS, 0, ctx->stream>>>(p, (u64 *)ctx->dist_keys.p, (u32 *)ctx->dist_counts.p, out_cap, (u32 *)ctx->sk_first.p);
+                    else if (k == 32) sk_bucket2_kernel<32, false><<<g3, SK_ROLL_THREADS, 0, ctx->stream>>>(p, (u64 *)ctx->dist_keys.p, (u32 *)ctx->dist_counts.p, out_cap, nullptr);
+                    else sk_bucket2_kernel<0, false><<<g3, SK_ROLL_THREADS, 0, ctx->stream>>>(p, (u64 *)ctx->dist_keys.p, (u32 *)ctx->dist_counts.p, out_cap, nullptr);
+                }
+                else if (want_pos) sk_bucket_kernel<0, true><<<g3, SK_ROLL_THREADS, 0, ctx->stream>>>(p, (u64 *)ctx->dist_keys.p, (u32 *)ctx->dist_counts.p, out_cap, (u32 *)ctx->sk_first.p);
                 else if (k == 32) sk_bucket_kernel<32, false><<<g3, SK_ROLL_THREADS, 0, ctx->stream>>>(p, (u64 *)ctx->dist_keys.p, (u32 *)ctx->dist_counts.p, out_cap, nullptr);
                 else sk_bucket_kernel<0, false><<<g3, SK_ROLL_THREADS, 0, ctx->stream>>>(p, (u64 *)ctx->dist_keys.p, (u32 *)ctx->dist_counts.p, out_cap, nullptr);
                 t3.stop();
@@ -728,7 +738,7 @@ static int count_superk(pb_ctx *ctx, unsigned k, bool *done, bool want_pos = fal
                                     (u64)(uintptr_t)p.bucket2, (u64)(uintptr_t)p.cursor2, (u64)(uintptr_t)p.flag2, (u64)(uintptr_t)p.fallback.slots, p.fallback.mask,
                                     (u64)(uintptr_t)p.spill, p.spill_cap, (u64)(uintptr_t)p.scalars, (u64)(uintptr_t)p.hist, (u64)(uintptr_t)ctx->packed.p, (u64)(uintptr_t)mask,
                                     ctx->stream_len, nw64, (u64)g1, (u64)g3, (u64)blocks_per_sub, (u64)nb1, (u64)dig_bytes, (u64)meta_bytes, (u64)(uintptr_t)ctx->dist_keys.p,
-                                    (u64)(uintptr_t)ctx->dist_counts.p, out_cap, (u64)(uintptr_t)ctx->h_hist, (u64)(uintptr_t)ctx->h_scalars};
+                                    (u64)(uintptr_t)ctx->dist_counts.p, out_cap, (u64)(uintptr_t)ctx->h_hist, (u64)(uintptr_t)ctx->h_scalars, (u64)ctx->opt_bucket_form};
             const bool want_graph = ctx->opt_graph && !want_pos && !ctx->opt_verbose;
             ctx->stage_ms["graph_replay"] = 0.f;
             if (want_graph && ctx->sk_graph && key == ctx->sk_graph_key) {
@@ -776,8 +786,10 @@ static int count_superk(pb_ctx *ctx, unsigned k, bool *done, bool want_pos = fal
         }
         if (ctx->opt_verbose)
             fprintf(stderr, "[pbgpu] super-k-mer pass: k %u, 2^%u buckets (l1 %u), cap1 %llu cap2 %u: windows %llu, records %llu, distinct %llu, flagged buckets %llu, "
-                            "spilled records %llu, overflow %llu\n", k, B, p.l1, (unsigned long long)p.cap1, p.cap2, (unsigned long long)sc[0], (unsigned long long)sc[6],
-                    (unsigned long long)sc[4], (unsigned long long)sc[7], (unsigned long long)sc[8], (unsigned long long)sc[1]);
+                            "spilled records %llu, overflow %llu; buffers %.3f s (%.1f GB held), pass %.3f s\n", k, B, p.l1, (unsigned long long)p.cap1, p.cap2, (unsigned long long)sc[0], (unsigned long long)sc[6],
+                    (unsigned long long)sc[4], (unsigned long long)sc[7], (unsigned long long)sc[8], (unsigned long long)sc[1], alloc_s,
+                    (double)(ctx->part_bucket1.bytes + ctx->part_bucket2.bytes + ctx->dist_keys.bytes + ctx->dist_counts.bytes + ctx->table.bytes + ctx->part_spill.bytes) / 1e9,
+                    std::chrono::duration<double>(std::chrono::steady_clock::now() - t_attempt).count() - alloc_s);
 #ifdef SK_DBG
         if (ctx->opt_verbose) {
             unsigned long long v[5] = {0, 0, 0, 0, 0};
@@ -826,6 +838,25 @@ static int count_superk(pb_ctx *ctx, unsigned k, bool *done, bool want_pos = fal
         const bool all_in_lds = sc[7] + sc[8] == 0;                // then h_hist already holds the whole histogram
         if (want_pos && !all_in_lds) return PB_OK;                 // records that left the LDS path carry no position: the caller takes the probing kernel
         if (!all_in_lds) {
+            // the global table is sized NOW, from what the pass says goes through it (spilled records + the records of the flagged buckets,
+            // at the pass's own windows per record), instead of failing at 2^20 slots and repeating the whole pass with 16 x the table:
+            // a 5 Mbp genome at 1000x spills 1.3 % of its records on the first pass (one minimizer site per bucket: Poisson sizes)
+            {
+                const double wpr = sc[6] ? (double)sc[0] / (double)sc[6] : (double)p.w;
+                const double need = ((double)sc[8] + (double)sc[7] * (double)p.cap2) * wpr * 1.5;
+                u64 want = fcap;
+                while ((double)want < need && want < (1ull << 34)) want <<= 1;
+                if (want > fcap) {
+                    if ((rc = ensure(ctx, ctx->table, want * 16)) != PB_OK) return rc;
+                    if ((rc = ensure(ctx, ctx->dist_keys, (sc[4] + want) * 8, true)) != PB_OK) return rc;      // (no-ops while out_cap's head-room covers it)
+                    if ((rc = ensure(ctx, ctx->dist_counts, (sc[4] + want) * 4, true)) != PB_OK) return rc;
+                    fcap = want;
+                    ctx->table_cap = fcap;
+                    p.fallback = TableView<1>{(u64 *)ctx->table.p, fcap - 1};
+                    ctx->sk_fcap = fcap;
+                    ctx->sk_fcap_for = windows;
+                }
+            }
             StageTimer t4(ctx, "seg_compact");                     // (stage name kept for bench.py: flagged buckets through the global table)
             table_init_kernel<1><<<grid_for(fcap * 2, 256, 256 * 32), 256, 0, ctx->stream>>>(p.fallback.slots, fcap);
             sk_flagged_kernel<<<dim3(grid_for(nb2, 1, 1024), 16), 256, 0, ctx->stream>>>(p);
@@ -849,7 +880,7 @@ static int count_superk(pb_ctx *ctx, unsigned k, bool *done, bool want_pos = fal
             break;
         }
         if (sc[8] > p.spill_cap) return PB_OK;   // a few minimizers carry most of the input (tiny k, low-complexity reads): the direct path takes it
-        if (sc[8]) room2 = 6.0;         // (records spilled: a small genome at high coverage has ~1 minimizer site per bucket, sizes are Poisson)
+        if (sc[8]) { room2 = 6.0; ctx->sk_room6_for = windows; }        // (records spilled AND the table sized for them overflowed: larger buckets, remembered for this stream)
         fcap <<= 4;                     // the fallback table overflowed: retry with a larger one (remembered for the next pass over this stream)
         ctx->sk_fcap = fcap;
         ctx->sk_fcap_for = windows;
@@ -1185,7 +1216,11 @@ int pb_sk_count_records(pb_ctx *ctx, unsigned k, const void *dev_records, uint64
             const unsigned blocks_per_sub = (unsigned)std::min<u64>(std::max<u64>(exp_tiles / 4, 1), 64);
             sk_part2_raw16_kernel<false><<<dim3(blocks_per_sub, (unsigned)nb1), SK_THREADS, 0, ctx->stream>>>(p);
             const unsigned g3 = grid_for(nb2, 1, 256 * 16);
-            if (k == 32) sk_bucket_kernel<32, false><<<g3, SK_ROLL_THREADS, 0, ctx->stream>>>(p, (u64 *)ctx->dist_keys.p, (u32 *)ctx->dist_counts.p, out_cap, nullptr);
+            if (ctx->opt_bucket_form == 2) {
+                if (k == 32) sk_bucket2_kernel<32, false><<<g3, SK_ROLL_THREADS, 0, ctx->stream>>>(p, (u64 *)ctx->dist_keys.p, (u32 *)ctx->dist_counts.p, out_cap, nullptr);
+                else sk_bucket2_kernel<0, false><<<g3, SK_ROLL_THREADS, 0, ctx->stream>>>(p, (u64 *)ctx->dist_keys.p, (u32 *)ctx->dist_counts.p, out_cap, nullptr);
+            }
+            else if (k == 32) sk_bucket_kernel<32, false><<<g3, SK_ROLL_THREADS, 0, ctx->stream>>>(p, (u64 *)ctx->dist_keys.p, (u32 *)ctx->dist_counts.p, out_cap, nullptr);
             else sk_bucket_kernel<0, false><<<g3, SK_ROLL_THREADS, 0, ctx->stream>>>(p, (u64 *)ctx->dist_keys.p, (u32 *)ctx->dist_counts.p, out_cap, nullptr);
         }
         HIPCHK(hipGetLastError());

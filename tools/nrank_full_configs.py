@@ -60,7 +60,7 @@ def run(tag, args, files, td):
                     h.update(blk)
             outs[fn[len(tag) + 1:]] = {"md5": h.hexdigest(), "bytes": os.path.getsize(os.path.join(td, fn))}
     return {"argv": " ".join(["platanus_b assemble -k 32", *args]), "exit_status": p.returncode, "wall_s": wall, "stage_wall_s": stages, "outputs": outs,
-            "stderr_tail": p.stderr[-1500:] if p.returncode else None}
+            "stderr_tail": p.stderr[-1500:] if p.returncode else None, "pbgpu_lines": [ln for ln in p.stderr.splitlines() if ln.startswith("[pbgpu]")][:60]}
 
 
 def main():
@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--workers", type=int, default=16)
     ap.add_argument("--scale", type=float, default=1.0, help="fraction of the coverage (development: small runs of the same script)")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--only-g1", action="store_true", help="development: the one-GPU run only, stderr kept (with --extra \"-gpu_opt verbose=1\")")
+    ap.add_argument("--extra", default="", help="extra CLI arguments for every run")
     a = ap.parse_args()
     c = CONFIGS[a.config]
     cov = c["cov"] * a.scale
@@ -90,8 +92,10 @@ def main():
         plan = [("g1", []), ("n_records", ["-gpus", str(a.ranks), "-share_gpu"]), ("n_counts", ["-gpus", str(a.ranks), "-share_gpu", "-gpu_opt", "dist_design=1"])]
         if a.ranks2:
             plan.append(("n2_counts", ["-gpus", str(a.ranks2), "-share_gpu"]))
+        if a.only_g1:
+            plan = plan[:1]
         for tag, args in plan:
-            res["runs"][tag] = run(tag, [*c["extra"], *args], files, td)
+            res["runs"][tag] = run(tag, [*c["extra"], *a.extra.split(), *args], files, td)
             print(tag, "exit", res["runs"][tag]["exit_status"], "wall", round(res["runs"][tag]["wall_s"], 2), flush=True)
         ref = res["runs"]["g1"]["outputs"]
         nr = [t for t, _ in plan if t != "g1"]
