@@ -127,6 +127,7 @@ struct pb_ctx {
     u64 *h_scalars = nullptr;           // pinned u64[16]: the pass scalars of a replay
     u64 h_hist_hi = 65536;              // bins of h_hist at or beyond this are zero
     int opt_graph = 1;                  // pb_set_option("graph"): 0 = every pass launched kernel by kernel (with per-kernel timers)
+    int opt_bucket_blocks = 0;          // pb_set_option("sk_bucket_blocks"): grid of the bucket kernel (0 = 4096: sixteen per CU, each striding over its buckets)
     int opt_bucket_form = 2;            // pb_set_option("sk_bucket_form"): 1 = sk_bucket_kernel (chunks of 768 records, per-wave piece lists), 2 = sk_bucket2_kernel (whole bucket)
     u64 sk_owner_cap1 = 0;          // pb_sk_owner_records: records per owner region
     u64 exp_cur[64] = {0};           // start of every owner's segment in the export (pb_export_begin -> pb_export_copy)
@@ -343,6 +344,7 @@ static int *option_slot(pb_ctx *ctx, const std::string &n, long value)
     if (n == "grid_cap" && value >= 0 && value <= (1 << 20)) return &ctx->opt_grid_cap;
     if (n == "graph" && (value == 0 || value == 1)) return &ctx->opt_graph;
     if (n == "sk_bucket_form" && (value == 1 || value == 2)) return &ctx->opt_bucket_form;
+    if (n == "sk_bucket_blocks" && value >= 0 && value <= 65536) return &ctx->opt_bucket_blocks;
     return nullptr;
 }
 
@@ -696,7 +698,7 @@ static int count_superk(pb_ctx *ctx, unsigned k, bool *done, bool want_pos = fal
             // a few blocks per sub-stream, each striding over its tiles (most of cap1 is head-room: one block per tile would be mostly empty blocks)
             const u64 exp_tiles = (u64)(est_rec / (double)nb1) / SK2Q_RCAP + 1;
             const unsigned blocks_per_sub = (unsigned)std::min<u64>(std::max<u64>(exp_tiles / 4, 1), 64);
-            const unsigned g3 = grid_for(nb2, 1, 256 * 16);
+            const unsigned g3 = grid_for(nb2, 1, ctx->opt_bucket_blocks ? (unsigned)ctx->opt_bucket_blocks : 256 * 16);
             const size_t meta_bytes = (nb1 * SK_CUR1_STRIDE + 2 * nb2) * 4;
             const u64 *mask = cur_mask(ctx);
             if (!ctx->h_hist) HIPCHK(hipHostMalloc((void **)&ctx->h_hist, 65536 * 8, hipHostMallocDefault));
@@ -810,8 +812,12 @@ static int count_superk(pb_ctx *ctx, unsigned k, bool *done, bool want_pos = fal
             (void)hipMemcpyFromSymbol(cyc, HIP_SYMBOL(sk_dbg_cyc), 96);
             unsigned long long tot = 0;
             for (int i = 0; i < 12; ++i) tot += cyc[i];
-            static const char *nm[12] = {"bucket prologue", "wait for the records", "phase A", "barrier A", "scan + piece map", "keys + CAS + add", "parking", "clear + last flush", "barrier B", "emit", "", ""};
-            for (int i = 0; i < 10; ++i) fprintf(stderr, "[pbgpu]   wave cycles %-22s %5.1f %%\n", nm[i], 100.0 * (double)cyc[i] / (double)tot);
+            static const char *nm1[12] = {"bucket prologue", "wait for the records", "phase A", "barrier A", "scan + piece map", "keys + CAS + add", "parking", "clear + last flush", "barrier B", "emit", "", ""};
+            static const char *nm2[12] = {"loop top (next bucket's size)", "phase A (all records, piece list)", "barrier A", "phase B rounds", "barrier B", "clear record table", "emit: rows + counts", "emit: barrier 1",
+                                          "emit: scan + reservation + barrier 2", "emit: stores + histogram", "last flush of the parked keys", ""};
+            const char **nm = ctx->opt_bucket_form == 2 ? nm2 : nm1;
+            for (int i = 0; i < 11; ++i) fprintf(stderr, "[pbgpu]   wave cycles %-38s %5.1f %%\n", nm[i], 100.0 * (double)cyc[i] / (double)tot);
+            { unsigned long long z[12] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(sk_dbg_cyc), z, 96); }
             fprintf(stderr, "[pbgpu]   dbg (cumulative): slow-probe iterations %llu, queue flushes %llu, parked keys %llu, piece steps %llu, window inserts %llu\n", v[0], v[1], v[2], v[3], v[4]);
         }
 #endif
