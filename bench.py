@@ -42,7 +42,7 @@ K = 32
 SEED = 1
 BYTES_PER_INSTANCE = 0.25 + 8 * ((K + 31) // 32) + 4        # 12.25 B at k = 32
 HBM_PEAK_GBS = 8000.0                                        # MI355X_MICROARCH.md: 8 TB/s spec
-TRAFFIC_PROFILE = "r02_hbm_traffic_superk.json"              # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (tools/pmc_traffic.py)
+TRAFFIC_PROFILE = "r03_hbm_traffic_superk.json"              # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (tools/pmc_traffic.py)
 
 
 def _sha1(path):
@@ -57,11 +57,29 @@ def _write_workload(tmp):
     return os.path.join(tmp, "in_1.fq"), os.path.join(tmp, "in_2.fq")
 
 
+def _reference_counting_rate(tmp, f1, f2, threads, instances, tag):
+    """k-mers/s of the real reference's counting stage (makeKmerReadDistributionMT, between its own progress lines assemble.cpp:306 and :334)
+    on the given FASTQ pair with -t `threads`, reference default -m 16; the run is stopped behind the stage.  None if it did not get there."""
+    from oracle import pyoracle
+    cmd = [pyoracle.REF_BIN, "assemble", "-k", str(K), "-t", str(threads), "-m", "16", "-kmer_occ_only", "-tmp", tmp, "-o", os.path.join(tmp, "ref" + tag), "-f", f1, f2]
+    p = subprocess.Popen(cmd, stderr=subprocess.PIPE, stdout=subprocess.DEVNULL, text=True)
+    t0 = t1 = None
+    for line in p.stderr:
+        if line.startswith("K = ") and "saving kmers from reads" in line:
+            t0 = time.perf_counter()
+        elif line.startswith("AVE_READ_LEN="):
+            t1 = time.perf_counter()
+            break
+    p.kill()
+    p.wait()
+    return None if t0 is None or t1 is None else (instances / (t1 - t0), t1 - t0)
+
+
 def cpu_baseline(tmp, f1, f2):
     """Counting-stage rate of the CPU reference on the bench workload itself (rank 0, N=1 only): the real reference binary
-    (oracle/_ref/platanus_b, built from /root/reference by oracle/Makefile) with its defaults -m 16 and all host threads it can use
-    (-t min(8, cores): the reference's counting does not scale beyond that), timed between its own progress
-    lines around makeKmerReadDistributionMT (assemble.cpp:306,334); the run is stopped there."""
+    (oracle/_ref/platanus_b, built from /root/reference by oracle/Makefile) with its defaults -m 16 and -t min(8, cores) (the reference's
+    counting does not scale beyond that).  Beside it: -t 1 on a fifth of the coverage (the whole
+    set would take a minute and a half) and -t min(32, cores) on the whole set."""
     from oracle import pyoracle
     ncpu = os.cpu_count() or 1
     threads = min(8, ncpu)
@@ -69,20 +87,27 @@ def cpu_baseline(tmp, f1, f2):
     instances = 2 * n_pairs * (READ_LEN - K + 1)
     sample = f"the bench workload: {GENOME / 1e6:g} Mbp x {COVERAGE:.0f}x PE{READ_LEN} seed {SEED} ({2 * n_pairs} reads, {instances} {K}-mers), counting stage only"
     if pyoracle.have_reference():
-        cmd = [pyoracle.REF_BIN, "assemble", "-k", str(K), "-t", str(threads), "-m", "16", "-kmer_occ_only", "-tmp", tmp, "-o", os.path.join(tmp, "ref"), "-f", f1, f2]
-        p = subprocess.Popen(cmd, stderr=subprocess.PIPE, stdout=subprocess.DEVNULL, text=True)
-        t0 = t1 = None
-        for line in p.stderr:          # makeKmerReadDistributionMT runs between these two progress lines
-            if line.startswith("K = ") and "saving kmers from reads" in line:
-                t0 = time.perf_counter()      # assemble.cpp:306
-            elif line.startswith("AVE_READ_LEN="):
-                t1 = time.perf_counter()      # assemble.cpp:334
-                break
-        p.kill()
-        p.wait()
-        if t0 is not None and t1 is not None:
-            return {"value": instances / (t1 - t0), "unit": "k-mers/s", "cores": ncpu, "threads": threads, "kind": "reference",
-                    "sample": sample + f", -t {threads} -m 16 (reference defaults), {t1 - t0:.1f} s"}
+        r = _reference_counting_rate(tmp, f1, f2, threads, instances, "")
+        if r is not None:
+            out = {"value": r[0], "unit": "k-mers/s", "cores": ncpu, "threads": threads, "kind": "reference",
+                   "sample": sample + f", -t {threads} -m 16 (reference defaults), {r[1]:.1f} s"}
+            others = []
+            try:
+                from platanus_b_amd import synth
+                synth.write_pair_files(os.path.join(tmp, "fifth"), GENOME, COVERAGE / 5, SEED)
+                np5 = int(GENOME * COVERAGE / 5) // (2 * READ_LEN)
+                r1 = _reference_counting_rate(tmp, os.path.join(tmp, "fifth_1.fq"), os.path.join(tmp, "fifth_2.fq"), 1, 2 * np5 * (READ_LEN - K + 1), "t1")
+                if r1 is not None:
+                    others.append({"threads": 1, "value": r1[0], "sample": f"{GENOME / 1e6:g} Mbp x {COVERAGE / 5:.0f}x (a fifth of the coverage), {r1[1]:.1f} s"})
+                big = min(32, ncpu)
+                if big > threads:
+                    rb = _reference_counting_rate(tmp, f1, f2, big, instances, "tb")
+                    if rb is not None:
+                        others.append({"threads": big, "value": rb[0], "sample": f"the bench workload, {rb[1]:.1f} s"})
+            except Exception as e:
+                others.append({"error": str(e)})
+            out["other_thread_counts"] = others
+            return out
     # CPU port (oracle restatement, single thread) on a fifth of the coverage: the binary did not travel
     from platanus_b_amd import synth
     r1, r2 = synth.make_reads(GENOME, COVERAGE / 20, SEED)
@@ -235,6 +260,7 @@ def main():
                          "export (key,count) by owner, all_to_all, owner-side merge")
     ap.add_argument("--exchange-with-one-rank", action="store_true", help=argparse.SUPPRESS)      # tests: the N > 1 step on a world of one (RCCL to itself)
     ap.add_argument("--shard-shapes-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-graph", action="store_true", help="every pass kernel by kernel (pb_set_option graph=0): counter-collection runs of the profiler")
     ap.add_argument("--self-launch", action="store_true", help=argparse.SUPPRESS)                 # tests: take the N > 1 launch path with --gpus 1
     a = ap.parse_args()
     if a.shard_shapes_only:
@@ -284,6 +310,8 @@ def main():
         dist.broadcast_object_list(box, src=0)
         e2e_dir = box[0]
     g = GpuCounter(local_rank)
+    if a.no_graph:
+        g.set_option("graph", 0)
     genome = synth.make_genome(a.genome, SEED)
     chunk = 250_000
     lo0 = rank * pairs_per_rank
@@ -362,7 +390,7 @@ def main():
         achieved = instances * BYTES_PER_INSTANCE / (k_ms * 1e-3) / 1e9
         parts = {st: float(np.mean(v)) for st, v in stage_ms.items()}
         partitioned = parts["part1"] > 0
-        kernel = ("sk_part1_kernel + sk_part2_raw16_kernel + sk_bucket_kernel + sk_flagged_kernel (super-k-mer counting pass)"
+        kernel = ("sk_part1_kernel + sk_part2_raw16_kernel + sk_bucket2_kernel (+ sk_flagged_kernel when buckets overflow: none here) -- the super-k-mer counting pass"
                   if partitioned else "count_kernel<1> (direct global-atomic counting pass)")
         # HBM bytes per counting pass from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes of this same
         # command, corrected as MI355X_MICROARCH.md prescribes).  NOT measured by this run: read from the committed profile, and only

@@ -117,6 +117,10 @@ class GpuCounter:
         self.n_instances = 0
         self.n_distinct = 0
         self.n_retained = 0
+        try:
+            self.set_option("hist_zeroed", 1)          # every occ_hist array this class hands over is np.zeros
+        except PbError:
+            pass                                       # (a development build of the library from before the option)
         for name, value in self.default_options.items():
             self.set_option(name, value)
 
@@ -173,7 +177,7 @@ class GpuCounter:
 
     # ---- counter.h:154 makeKmerReadDistributionMT ---------------------------------------------------
     def make_kmer_read_distribution(self, k: int):
-        hist = np.empty(PB_OCC_BINS, dtype=np.uint64)          # (pb_count writes every bin)
+        hist = np.zeros(PB_OCC_BINS, dtype=np.uint64)          # (untouched zero pages; with "hist_zeroed" the library writes the non-zero head only)
         mx, ni, nd = C.c_uint64(), C.c_uint64(), C.c_uint64()
         self._chk(self.lib.pb_count(self.h, k, hist.ctypes.data, C.byref(mx), C.byref(ni), C.byref(nd)))
         self.k, self.occ_hist, self.max_occ = k, hist, mx.value

@@ -127,6 +127,7 @@ struct pb_ctx {
     u64 *h_scalars = nullptr;           // pinned u64[16]: the pass scalars of a replay
     u64 h_hist_hi = 65536;              // bins of h_hist at or beyond this are zero
     int opt_graph = 1;                  // pb_set_option("graph"): 0 = every pass launched kernel by kernel (with per-kernel timers)
+    int opt_hist_zeroed = 0;            // pb_set_option("hist_zeroed"): occ_hist arrays handed to the counting calls are all zero on entry
     int opt_bucket_blocks = 0;          // pb_set_option("sk_bucket_blocks"): grid of the bucket kernel (0 = 4096: sixteen per CU, each striding over its buckets)
     int opt_bucket_form = 2;            // pb_set_option("sk_bucket_form"): 1 = sk_bucket_kernel (chunks of 768 records, per-wave piece lists), 2 = sk_bucket2_kernel (whole bucket)
     u64 sk_owner_cap1 = 0;          // pb_sk_owner_records: records per owner region
@@ -345,6 +346,7 @@ static int *option_slot(pb_ctx *ctx, const std::string &n, long value)
     if (n == "graph" && (value == 0 || value == 1)) return &ctx->opt_graph;
     if (n == "sk_bucket_form" && (value == 1 || value == 2)) return &ctx->opt_bucket_form;
     if (n == "sk_bucket_blocks" && value >= 0 && value <= 65536) return &ctx->opt_bucket_blocks;
+    if (n == "hist_zeroed" && (value == 0 || value == 1)) return &ctx->opt_hist_zeroed;
     return nullptr;
 }
 
@@ -552,10 +554,16 @@ static int finish_count(pb_ctx *ctx, uint64_t *occ_hist, uint64_t *max_occ)
         HIPCHK(hipStreamSynchronize(ctx->stream));
         h = hv.data();
     }
+    // bins at or beyond `hi` are zero (a replayed pass says how far its counts reach): nothing to look at there, and -- option
+    // "hist_zeroed": the caller's array is zero already -- nothing to write (512 KB of fresh pages per call otherwise)
+    const u64 hi = h == ctx->h_hist && ctx->h_hist_valid ? std::min<u64>(ctx->h_hist_hi, PB_OCC_BINS) : PB_OCC_BINS;
     ctx->h_hist_valid = false;
     static_assert(sizeof(uint64_t) == sizeof(u64), "histogram bins are 64-bit");
-    if (occ_hist) memcpy(occ_hist, h, (size_t)PB_OCC_BINS * 8);
-    if (max_occ) { *max_occ = 0; for (int i = PB_COUNT_MAX; i > 0; --i) if (h[i]) { *max_occ = (u64)i; break; } }
+    if (occ_hist) {
+        memcpy(occ_hist, h, (size_t)hi * 8);
+        if (hi < PB_OCC_BINS && !ctx->opt_hist_zeroed) memset(occ_hist + hi, 0, (size_t)(PB_OCC_BINS - hi) * 8);
+    }
+    if (max_occ) { *max_occ = 0; for (int i = (int)std::min<u64>(PB_COUNT_MAX, hi - 1); i > 0; --i) if (h[i]) { *max_occ = (u64)i; break; } }
     return PB_OK;
 }
 

@@ -289,6 +289,26 @@ def test_edit_distances_against_plain_dp():
         assert int(got[p]) == prev[len(b)], p
 
 
+def test_edit_distances_long_branches():
+    """Beyond one strip and beyond the wave kernel's LDS: a 100-base branch against a 20,000-base one (313 strips of 64 columns), and two
+    branches of 9,000 bases (both sides over ED_MAXROWS = 8192: the lane-per-pair kernel with its rows in global memory); distances known by
+    construction (substitutions far apart in random sequence; a prefix against the whole)."""
+    rng = np.random.default_rng(17)
+    a = rng.integers(0, 4, 100).astype(np.uint8)
+    b = np.concatenate([a, rng.integers(0, 4, 19_900).astype(np.uint8)])
+    c = rng.integers(0, 4, 9_000).astype(np.uint8)
+    d = c.copy()
+    for pos in (100, 2_000, 4_500, 7_000, 8_900):
+        d[pos] = (d[pos] + 1) & 3
+    e = rng.integers(0, 4, 8_192).astype(np.uint8)                    # exactly ED_MAXROWS rows: still the wave kernel
+    f = np.delete(e, [10, 5_000])
+    seqs = [a, b, c, d, b, a, e, f]
+    off = np.concatenate([[0], np.cumsum([len(x) for x in seqs])]).astype(np.uint64)
+    g = GpuCounter(0)
+    got = g.edit_distances(np.concatenate(seqs), off)
+    assert [int(x) for x in got] == [19_900, 5, 19_900, 2]
+
+
 @pytest.mark.parametrize("k", [21, 32, 45, 100])
 def test_node_cleaning_decisions_against_plain_loops(k):
     """pb_nodes_clean_decide on random node sets: junctions with tips, real branches and junction-junction links on both sides; the

@@ -10,7 +10,7 @@ import csv
 import json
 import sys
 
-KERNELS = ("sk_part1_kernel", "sk_part2_raw16_kernel", "sk_part2_raw12_kernel", "sk_part2_kernel", "sk_bucket_kernel", "sk_flagged_kernel", "hist_array_kernel")
+KERNELS = ("sk_part1_kernel", "sk_part2_raw16_kernel", "sk_part2_raw12_kernel", "sk_part2_kernel", "sk_bucket_kernel", "sk_bucket2_kernel", "sk_flagged_kernel", "hist_array_kernel")
 
 
 def load(path, counter):

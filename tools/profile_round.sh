@@ -1,8 +1,8 @@
 #!/bin/bash
 # Round profiles (run on the GPU box from the repo root): kernel trace of bench.py, SQ counter passes, HBM traffic passes.
-# usage: bash tools/profile_round.sh r02     -> gpurun_out/prof_r02/...; copy the summaries into profiles/ afterwards (tools/profile_collect.py)
+# usage: bash tools/profile_round.sh r03     -> gpurun_out/prof_r03/...; copy the summaries into profiles/ afterwards (tools/profile_collect.py)
 set -e
-tag=${1:-r02}
+tag=${1:-r03}
 out=gpurun_out/prof_$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
@@ -18,7 +18,7 @@ python3 tools/pmc_sq_summary.py "$out/pmc_sq" "$out/pmc_sq_summary.json"
 echo "sq done"
 # 4. HBM traffic: FETCH_SIZE and WRITE_SIZE in separate passes
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$out/pmc_$c" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > "$out/pmc_$c.log" 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$out/pmc_$c" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph > "$out/pmc_$c.log" 2>&1
 done
 f=$(ls $out/pmc_FETCH_SIZE/*/*counter_collection.csv | head -1); w=$(ls $out/pmc_WRITE_SIZE/*/*counter_collection.csv | head -1)
 python3 tools/pmc_traffic.py "$f" "$w" "$out/hbm_traffic_superk.json" > "$out/pmc_traffic.log"
