@@ -71,6 +71,15 @@ int         pb_device_info(const pb_ctx *ctx, char *name, size_t name_cap, int *
  * reads are packed to 2 bits/base plus a 1-bit unknown-base mask (kernel K1).  Append order = the order of
  * the reference's temp file 0 at -t 1 (file 1's reads, then file 2's, ...). */
 int pb_reads_append(pb_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads, int ascii);
+/* SURVEY 8(f) row 3 -- the read ingest on the device (replaces the host-side line parser in front of pb_reads_append; reference:
+ * assemble.cpp:790-986, the FASTA / FASTQ line rules of Assemble::readFastaSingle... / readFastqSingle...).  `bytes` is a piece of an
+ * uncompressed read file that starts at a record-mark line ('@' / '>' at a line start) -- or the file's first piece (first_piece != 0:
+ * its first line is the format line checkFileFormat has looked at) --, smaller than 4 GiB; last_piece != 0: the piece ends the file (the
+ * reference's unconditional trailing flush).  Newline positions, line classes, the sequence lines of every record and the read offsets are
+ * found by map / prefix-scan kernels; the reads are then appended exactly as pb_reads_append(ascii = 1) appends the host parser's.
+ * PB_ERANGE (nothing appended) if a read has 500000 bases or more.  pb_reads_starts: stream position of every read + final sentinel. */
+int pb_reads_append_raw(pb_ctx *ctx, const uint8_t *bytes, uint64_t n_bytes, int is_fastq, int first_piece, int last_piece, uint64_t *n_reads, uint64_t *n_bases);
+int pb_reads_starts(const pb_ctx *ctx, uint64_t *starts, uint64_t cap);
 /* optional: announce how much pb_reads_append calls will bring in total, so that the packed stream is allocated once */
 int pb_reads_reserve(pb_ctx *ctx, uint64_t n_bases, uint64_t n_reads);
 int pb_reads_clear(pb_ctx *ctx);

@@ -54,6 +54,8 @@ def load_library() -> C.CDLL:
     lib.pb_set_option.argtypes = [vp, C.c_char_p, C.c_long]
     lib.pb_device_info.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), u64p]
     lib.pb_reads_append.argtypes = [vp, vp, vp, C.c_uint64, C.c_int]
+    lib.pb_reads_append_raw.argtypes = [vp, vp, C.c_uint64, C.c_int, C.c_int, C.c_int, u64p, u64p]
+    lib.pb_reads_starts.argtypes = [vp, vp, C.c_uint64]
     lib.pb_reads_clear.argtypes = [vp]
     lib.pb_reads_info.argtypes = [vp, u64p, u64p]
     lib.pb_reads_length_hist.argtypes = [vp, vp, C.c_uint64]
@@ -159,6 +161,21 @@ class GpuCounter:
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         n = offsets.size - 1
         self._chk(self.lib.pb_reads_append(self.h, bases.ctypes.data, offsets.ctypes.data, n, 1 if ascii else 0))
+
+    def reads_append_raw(self, file_bytes, fastq: bool, first_piece: bool = True, last_piece: bool = True):
+        """SURVEY 8(f) row 3: the bytes of (a piece of) a FASTA / FASTQ file, parsed on the device (assemble.cpp:790-986's line rules);
+        returns (reads, bases) appended."""
+        b = np.frombuffer(file_bytes, dtype=np.uint8) if not isinstance(file_bytes, np.ndarray) else np.ascontiguousarray(file_bytes, dtype=np.uint8)
+        nr, nb = C.c_uint64(), C.c_uint64()
+        self._chk(self.lib.pb_reads_append_raw(self.h, b.ctypes.data if b.size else None, b.size, 1 if fastq else 0, 1 if first_piece else 0, 1 if last_piece else 0,
+                                               C.byref(nr), C.byref(nb)))
+        return nr.value, nb.value
+
+    def reads_starts(self) -> np.ndarray:
+        n, _ = self.reads_info()
+        out = np.zeros(n + 1, dtype=np.uint64)
+        self._chk(self.lib.pb_reads_starts(self.h, out.ctypes.data, n + 1))
+        return out
 
     def reads_append_matrix(self, codes: np.ndarray):
         """codes: [n_reads, read_len] uint8 matrix (all reads the same length)."""

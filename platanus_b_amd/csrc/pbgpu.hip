@@ -168,6 +168,7 @@ struct pb_ctx {
     unsigned ctable_k = 0;
     DevBuf chain_work, chain_rec, chain_seq;     // K7 chain compaction
     DevBuf layout_work, layout_slots, layout_out, scan_sums, slot_blk;   // CT8 exact PREFIX_kmer_occ.bin layout
+    DevBuf raw_bytes, raw_work, raw_tiles, raw_s3, raw_hist;              // pb_reads_append_raw: file bytes and the per-line arrays of the device-side parse
     u64 layout_records = 0;
     u64 n_chains = 0, chain_seq_words = 0;
     void *chain_ptrs[2] = {nullptr, nullptr};
@@ -314,6 +315,7 @@ void pb_destroy(pb_ctx *ctx)
     release(ctx->node_work); release(ctx->node_table); release(ctx->index_table); release(ctx->node_mark); release(ctx->node_idx); release(ctx->node_rec); release(ctx->nmask_cur); release(ctx->alive); release(ctx->d_read_start);
     release(ctx->contig_packed); release(ctx->contig_mask); release(ctx->ctable);
     release(ctx->chain_work); release(ctx->chain_rec); release(ctx->chain_seq);
+    release(ctx->raw_bytes); release(ctx->raw_work); release(ctx->raw_tiles); release(ctx->raw_s3); release(ctx->raw_hist);
     release(ctx->layout_work); release(ctx->layout_slots); release(ctx->layout_out); release(ctx->scan_sums); release(ctx->slot_blk);
     for (auto &s : ctx->scratch) release(s);
     delete ctx->copy_pool;
@@ -1645,3 +1647,4 @@ int pb_merge_end(pb_ctx *ctx, uint64_t *occ_hist, uint64_t *max_occ, uint64_t *n
 #include "kmer_occ_layout.inc"
 #include "node_kernels.inc"
 #include "dist.inc"
+#include "raw_parse.inc"
