@@ -468,7 +468,24 @@ int run_assemble_gpu(const GpuAssembleOptions &opt)
     std::vector<std::vector<ParsedPiece>> fpieces(nf);
     std::vector<std::exception_ptr> ferr(nf);
     const unsigned hw = std::max(2u, std::thread::hardware_concurrency());
-    for (size_t base = 0; base < nf; base += 8) {
+    if (opt.device_parse) {
+        // -device_parse: the bytes of this rank's range of every file go to the device as they are, pieces of at most
+        // 1 GiB cut at record marks; newline index, line rules and read offsets are kernels (csrc/raw_parse.inc)
+        {
+            Tick t("wait for the device context");
+            d.ready();
+        }
+        for (size_t i = 0; i < nf; ++i) {
+            Tick t("read files + device-side parse (H2D + device)");
+            std::vector<ParsedPiece> none;
+            read_file(opt.files[i], none, 1, (unsigned)opt.rank, (unsigned)std::max(opt.world, 1), [&](const char *p, size_t nb, bool fq, bool first, bool last) {
+                const int rc = pb_reads_append_raw(d.ctx, (const uint8_t *)p, nb, fq ? 1 : 0, first ? 1 : 0, last ? 1 : 0, nullptr, nullptr);
+                if (rc == PB_ERANGE) throw read_too_long();              // common.h:465-467, as the host parser throws it
+                d.chk(rc);
+            });
+        }
+    }
+    for (size_t base = 0; base < (opt.device_parse ? 0 : nf); base += 8) {
         const size_t hi_f = std::min(nf, base + 8);
         const unsigned per_file = std::max<unsigned>(1, std::min(16u, hw) / (unsigned)(hi_f - base));
         {

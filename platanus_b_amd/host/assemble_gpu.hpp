@@ -23,6 +23,7 @@ struct GpuAssembleOptions {
     bool repeat = false;
     bool verbose = true;
     int device = 0;                      // not in the reference: which GPU
+    bool device_parse = false;           // not in the reference: the FASTA / FASTQ line rules applied on the device (pb_reads_append_raw) instead of by host threads
     // not in the reference: N ranks (processes) on one run, reads range-partitioned over them
     int rank = 0, world = 1;
     void *shared = nullptr;              // pb_dist_shared_create's block, made before the ranks were forked

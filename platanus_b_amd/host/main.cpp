@@ -42,6 +42,7 @@ static void usage()
               << "                           are exchanged by key owner and the retained sets gathered over RCCL before every graph stage; same output files\n"
               << "    -share_gpu           : with -gpus N: all ranks on device -gpu, records exchanged through shared host memory (tests)\n"
               << "    -comm STR            : with -gpus N: rccl (default) or host (shared host memory instead of RCCL)\n"
+              << "    -device_parse        : uncompressed read files are parsed on the device (their bytes are uploaded as they are); default: by host threads\n"
               << "    -gpu_opt NAME=INT    : pb_set_option of libpbgpu (selects device code paths; results do not change)\n"
               << "    (-repeat is refused: the reference itself crashes in that mode, DESIGN.md section 1)\n"
               << "\n\nOutputs:\n    PREFIX_contig.fa\n    PREFIX_kmerFrq.tsv\n\nNote, PREFIX is specified by -o\n" << std::endl;
@@ -206,6 +207,7 @@ int main(int argc, char **argv)
         else if (a == "-gpu") o.device = atoi(val().c_str());
         else if (a == "-gpus") n_ranks = atoi(val().c_str());
         else if (a == "-share_gpu") share_gpu = true;
+        else if (a == "-device_parse") o.device_parse = true;
         else if (a == "-comm") comm = val();
         else if (a == "-gpu_opt") {              // NAME=VALUE for pb_set_option (which kernels run, never what they return)
             const std::string nv = val();

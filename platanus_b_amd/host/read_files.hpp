@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <exception>
+#include <functional>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -95,7 +96,12 @@ inline bool check_file_format(const char *data, size_t size, bool &fastq)
 // part / parts (N ranks on one run): the file is cut into `parts` byte ranges at record-mark lines -- the same rule as the thread
 // pieces below, so the concatenation of all parts' pieces is the sequential result -- and only range `part` is parsed.  Every rank
 // computes the same cuts from the same bytes; a compressed file is still decompressed by every rank (one serial stream).
-inline void read_file(const std::string &path, std::vector<ParsedPiece> &pieces, unsigned max_threads, unsigned part = 0, unsigned parts = 1)
+// raw_sink (optional): instead of parsing, the pieces of this rank's range are handed over as bytes -- (data, size, fastq, first piece of
+// the file, piece that owns the file's end), in file order, cut at record marks and no larger than raw_piece_max -- for the device-side
+// parser (pb_reads_append_raw); `pieces` stays empty.
+typedef std::function<void(const char *, size_t, bool, bool, bool)> RawSink;
+inline void read_file(const std::string &path, std::vector<ParsedPiece> &pieces, unsigned max_threads, unsigned part = 0, unsigned parts = 1,
+                      const RawSink &raw_sink = nullptr, size_t raw_piece_max = 1u << 30)
 {
     // compression by content, as `file -bL` tells the reference (common.cpp:88-118), not by the name
     FILE *fp = fopen(path.c_str(), "rb");
@@ -185,6 +191,17 @@ inline void read_file(const std::string &path, std::vector<ParsedPiece> &pieces,
         if (lo >= hi && !(owns_end && lo == 0)) { pieces.clear(); return; }
     }
     const size_t span = hi - lo;
+    if (raw_sink) {
+        pieces.clear();
+        size_t at = lo;
+        while (at < hi) {
+            size_t end = hi;
+            if (hi - at > raw_piece_max) { end = std::min(next_mark_line(at + raw_piece_max / 2), hi); if (end <= at) end = hi; }
+            raw_sink(data + at, end - at, fastq, at == 0, owns_end && end == hi);
+            at = end;
+        }
+        return;
+    }
     unsigned n = (unsigned)std::min<size_t>(std::max<unsigned>(max_threads, 1), span / piece_bytes + 1);
     std::vector<size_t> cut{lo};
     for (unsigned i = 1; i < n; ++i) {

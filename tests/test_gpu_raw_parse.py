@@ -116,3 +116,45 @@ def test_device_parse_edge_cases():
         g.reads_append_raw(b">s\n" + b"A" * 500_000 + b"\n", False)
     assert g.reads_info() == (0, 0)
     assert g.reads_append_raw(b">s\n" + b"A" * 499_999 + b"\n", False) == (1, 499_999)
+
+
+@pytest.mark.parametrize("name,run,extra", [("c2", "multik_n2", []), ("c1", "multik", ["-gpus", "3", "-share_gpu"]), ("het", "u1", [])])
+def test_cli_device_parse_writes_the_reference_files(name, run, extra, manifest, tmp_path):
+    """`assemble -device_parse`: the read files' bytes go to the device as they are (this rank's byte range, cut at record marks) and
+    the line rules run there; the output files must still be the real reference's (N bases, -n 2, 3 ranks, -u 1)."""
+    import hashlib
+    import os
+    import subprocess
+    from conftest import ROOT
+    from platanus_b_amd import synth
+    case = manifest[name]
+    info = case["runs"][run]
+    synth.write_pair_files(str(tmp_path / "in"), case["genome"], case["cov"], case["seed"], err=case["err"], n_rate=case["n_rate"], het=case.get("het", 0.0))
+    cli = os.path.join(ROOT, "platanus_b_amd", "bin", "platanus_b")
+    p = subprocess.run([cli, "assemble", *info["args"], *extra, "-device_parse", "-o", "out", "-f", "in_1.fq", "in_2.fq"], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    for fn, meta in info["files"].items():
+        assert hashlib.md5(open(tmp_path / fn, "rb").read()).hexdigest() == meta["md5"], fn
+
+
+def test_cli_device_parse_on_awkward_files(tmp_path):
+    """The awkward FASTQ / FASTA files of the host-reader tests (multi-line sequences, quality lines that start with '@' or '+', headers
+    without a sequence, no final newline, gzip) through the CLI: -device_parse and the host parser must write the same files."""
+    import filecmp
+    import os
+    import subprocess
+    from conftest import ROOT
+    rng = np.random.default_rng(3)
+    _tricky_fastq(str(tmp_path / "a.fq"), rng)
+    _multiline_fasta(str(tmp_path / "b.fa"), rng)
+    subprocess.run(["gzip", "-k", str(tmp_path / "a.fq")], check=True)
+    cli = os.path.join(ROOT, "platanus_b_amd", "bin", "platanus_b")
+    for files in (["a.fq", "b.fa"], ["a.fq.gz", "b.fa"]):
+        outs = []
+        for tag, extra in (("h", []), ("d", ["-device_parse"]), ("d2", ["-device_parse", "-gpus", "2", "-share_gpu"])):
+            p = subprocess.run([cli, "assemble", "-k", "21", "-n", "1", *extra, "-o", tag, "-f", *files], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+            assert p.returncode == 0, p.stderr[-2000:]
+            outs.append(tag)
+        for tag in outs[1:]:
+            for fn in ("_contig.fa", "_21merFrq.tsv"):
+                assert filecmp.cmp(tmp_path / ("h" + fn), tmp_path / (tag + fn), shallow=False), (files, tag, fn)

@@ -7,9 +7,11 @@ import sys; sys.path.insert(0,'.')
 from platanus_b_amd import synth
 synth.write_pair_files('$D/in', ${1:-5000000}, ${2:-100}, 1)
 "
+# usage: tools/time_cfg3.sh [genome] [coverage] [extra CLI arguments, e.g. -device_parse]
+EXTRA="${@:3}"
 for i in 1 2 3; do
   t0=$(date +%s.%N)
-  PB_TIMING=1 platanus_b_amd/bin/platanus_b assemble -k 32 -o $D/out -f $D/in_1.fq $D/in_2.fq 2> $D/log$i > /dev/null
+  PB_TIMING=1 platanus_b_amd/bin/platanus_b assemble -k 32 $EXTRA -o $D/out -f $D/in_1.fq $D/in_2.fq 2> $D/log$i > /dev/null
   t1=$(date +%s.%N)
   python3 -c "
 import sys, re
