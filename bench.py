@@ -169,7 +169,12 @@ def end_to_end_n_ranks(tmp, world):
     md5 = {}
     for name, tag, args in ((f"assemble_gpus{n_cli}_wall_s", "n", ["-gpus", str(n_cli), *extra]), ("assemble_gpus1_wall_s", "s", [])):
         t0 = time.perf_counter()
-        r = subprocess.run([cli, "assemble", "-k", str(K), *args, "-o", os.path.join(tmp, tag), "-f", *files], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+        try:
+            r = subprocess.run([cli, "assemble", "-k", str(K), *args, "-o", os.path.join(tmp, tag), "-f", *files], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True,
+                               timeout=900)
+        except subprocess.TimeoutExpired:
+            out["error"] = f"{name}: no result within 900 s (stopped)"      # (the bench line must not wait for a run that does not end)
+            return out
         out[name] = time.perf_counter() - t0
         if r.returncode != 0:
             out["error"] = f"{name}: exit status {r.returncode}: {r.stderr[-400:]}"
