@@ -746,3 +746,53 @@ def test_superkmer_random_differential():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_count.py"), "24", "11"], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     assert "24 cases, 0 mismatches" in p.stdout
+
+
+@pytest.mark.parametrize("form", [1, 2])
+@pytest.mark.parametrize("bits", [3, 11, 15])
+def test_superkmer_both_forms_of_the_bucket_kernel(form, bits, gpu, oracle_built, monkeypatch):
+    """r3: sk_bucket2_kernel (the whole bucket in one round, block-wide piece list: the default) and sk_bucket_kernel (chunks, per-wave piece
+    lists) against the oracle.  With 8 buckets a bucket holds thousands of distinct records: the second form's record table (1024 slots)
+    fills up and records put their windows straight into the table of keys -- on the same slot sequence the pieces use (a first version
+    used another one and counted four keys of 60.8 M twice); then the table of keys overflows and the bucket goes through the global table."""
+    from platanus_b_amd import synth
+    monkeypatch.setitem(GpuCounter.default_options, "count_path", COUNT_PATH["superk"])
+    monkeypatch.setitem(GpuCounter.default_options, "sk_bucket_bits", bits)
+    monkeypatch.setitem(GpuCounter.default_options, "sk_bucket_form", form)
+    r1, r2 = synth.make_reads(80_000, 60, seed=300 + bits, err=0.01, n_rate=0.001)
+    _superk_case(gpu, oracle_built, np.concatenate([r1, r2]), 32, cutoffs=(1, 3))
+    _superk_case(gpu, oracle_built, np.concatenate([r1, r2]), 27, cutoffs=(2,))
+
+
+def test_counting_pass_replayed_as_a_graph(gpu, oracle_built, monkeypatch):
+    """r3: the k <= 32 pass is captured on its first run over a set of buffers and replayed as one graph launch afterwards; a replay must
+    give what the kernel-by-kernel pass gives (histogram head copied out with the scalars, tail fetched only when counts reach beyond it --
+    here a 3000-fold repeat does), and anything that moves a buffer (more reads, another k) must end in a new capture, not a stale replay."""
+    from platanus_b_amd import synth
+    monkeypatch.setitem(GpuCounter.default_options, "count_path", COUNT_PATH["superk"])
+    r1, r2 = synth.make_reads(60_000, 50, seed=77, n_rate=0.001)
+    rep = np.tile(r1[:1], (3000, 1))                       # one read 3000 times: counts beyond the 1024 bins of the head
+    codes = np.concatenate([r1, r2, rep])
+    n, L = codes.shape
+    off = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
+    oc = _oracle(codes, off, 32, oracle_built)
+    ohist, omax = oc.occ_hist()
+    assert omax > 2000
+    g = gpu(0)
+    g.reads_append_matrix(codes)
+    seen = []
+    for it in range(4):
+        hist = g.make_kmer_read_distribution(32)
+        seen.append(g.kernel_ms("graph_replay"))
+        assert np.array_equal(hist, ohist) and g.max_occ == omax, it
+    assert seen[0] == 0 and seen[1] == 1 and seen[3] == 1           # captured by the first pass, replayed by the others
+    g.set_option("graph", 0)
+    assert np.array_equal(g.make_kmer_read_distribution(32), ohist) and g.kernel_ms("graph_replay") == 0
+    g.set_option("graph", 1)
+    o25 = _oracle(codes, off, 25, oracle_built)
+    assert np.array_equal(g.make_kmer_read_distribution(25), o25.occ_hist()[0])                 # another k: other kernels, other buffers
+    assert np.array_equal(g.make_kmer_read_distribution(32), ohist)
+    g.reads_append_matrix(r2[:500])                        # more reads: the stream moves
+    o2 = _oracle(np.concatenate([codes, r2[:500]]), np.arange(n + 501, dtype=np.uint64) * np.uint64(L), 32, oracle_built)
+    for it in range(2):
+        assert np.array_equal(g.make_kmer_read_distribution(32), o2.occ_hist()[0]), it
