@@ -19,7 +19,7 @@ def main():
             acc[name]["_wg"] = [float(r["Workgroup_Size"])]
     out = {}
     for k, v in acc.items():
-        if not any(k.startswith(p) for p in ("sk_", "mg_", "hist_", "first_occ", "occ_", "part_")):
+        if not any(k.startswith(p) for p in ("sk_", "sk2_", "mg_", "hist_", "first_occ", "occ_", "part_", "raw_")):
             continue
         m = {c: sum(x) / len(x) for c, x in v.items()}
         m["_ms_profiled"] = sum(dur[k]) / len(dur[k])
