@@ -128,7 +128,7 @@ struct pb_ctx {
     u64 h_hist_hi = 65536;              // bins of h_hist at or beyond this are zero
     int opt_graph = 1;                  // pb_set_option("graph"): 0 = every pass launched kernel by kernel (with per-kernel timers)
     int opt_hist_zeroed = 0;            // pb_set_option("hist_zeroed"): occ_hist arrays handed to the counting calls are all zero on entry
-    int opt_bucket_blocks = 0;          // pb_set_option("sk_bucket_blocks"): grid of the bucket kernel (0 = 4096: sixteen per CU, each striding over its buckets)
+    int opt_bucket_blocks = 0;          // pb_set_option("sk_bucket_blocks"): grid of the bucket kernel (0 = 8192, each block striding over its buckets)
     int opt_bucket_form = 2;            // pb_set_option("sk_bucket_form"): 1 = sk_bucket_kernel (chunks of 768 records, per-wave piece lists), 2 = sk_bucket2_kernel (whole bucket)
     u64 sk_owner_cap1 = 0;          // pb_sk_owner_records: records per owner region
     u64 exp_cur[64] = {0};           // start of every owner's segment in the export (pb_export_begin -> pb_export_copy)
@@ -708,7 +708,7 @@ static int count_superk(pb_ctx *ctx, unsigned k, bool *done, bool want_pos = fal
             // a few blocks per sub-stream, each striding over its tiles (most of cap1 is head-room: one block per tile would be mostly empty blocks)
             const u64 exp_tiles = (u64)(est_rec / (double)nb1) / SK2Q_RCAP + 1;
             const unsigned blocks_per_sub = (unsigned)std::min<u64>(std::max<u64>(exp_tiles / 4, 1), 64);
-            const unsigned g3 = grid_for(nb2, 1, ctx->opt_bucket_blocks ? (unsigned)ctx->opt_bucket_blocks : 256 * 16);
+            const unsigned g3 = grid_for(nb2, 1, ctx->opt_bucket_blocks ? (unsigned)ctx->opt_bucket_blocks : 256 * 32);      // (r3 sweep, cfg2: 512 blocks 1.21 ms, 4096 1.17, 8192 1.13-1.16, 32768 1.26)
             const size_t meta_bytes = (nb1 * SK_CUR1_STRIDE + 2 * nb2) * 4;
             const u64 *mask = cur_mask(ctx);
             if (!ctx->h_hist) HIPCHK(hipHostMalloc((void **)&ctx->h_hist, 65536 * 8, hipHostMallocDefault));
