@@ -422,7 +422,7 @@ def main():
                 traffic_source = {"file": "profiles/" + TRAFFIC_PROFILE, "kernels_sha1": prof.get("kernels_sha1"), "measured_by_this_run": False}
         # the timed loop's own result: the occurrence distribution of the last step as the reference's TSV, against the reference's md5
         hist_ok = None
-        if a.genome == GENOME and world == 1:
+        if a.genome == GENOME and world == 1 and timed_hist is not None:
             import hashlib
             tsv = "".join(f"{i}\t{int(timed_hist[i])}\n" for i in range(1, timed_max + 1))
             man = json.load(open(os.path.join(ROOT, "tests", "golden", "manifest.json")))["cfg3"]["runs"]["multik"]["files"]["out_32merFrq.tsv"]
