@@ -176,7 +176,7 @@ void make_initial_from_device(Graph<W> &gr, const DeviceGraphInput<W> &in)
             for (u64 j = 0; j < lseq.size(); ++j) st.set(rn + k + j, lseq[j]);
             st.coverage = (u16)(static_cast<double>(sum) / static_cast<double>(st.length) + 0.5);
             st.out = (uint8_t)((lfl << 4) | rfl);
-            gr.insert_straight(st);
+            gr.insert_straight(std::move(st));
         }
     }
 }
@@ -262,7 +262,7 @@ void make_initial_from_chains(Graph<W> &gr, const DeviceGraphInput<W> &in, const
                 st.seq.resize((len + k + 31) / 32, 0);                // binstr_t(length + k) word count (graph.h:559)
                 st.coverage = (u16)(static_cast<double>(cs.sum[c]) / static_cast<double>(len) + 0.5);
                 st.out = (uint8_t)((lfl << 4) | rfl);
-                gr.insert_straight(st);
+                gr.insert_straight(std::move(st));
                 continue;
             }
             visited[s.i] = 1;
@@ -334,7 +334,7 @@ void make_initial_from_chains(Graph<W> &gr, const DeviceGraphInput<W> &in, const
             for (u64 j = 0; j < lseq.size(); ++j) st.set(rn + k + j, lseq[j]);
             st.coverage = (u16)(static_cast<double>(sum) / static_cast<double>(st.length) + 0.5);
             st.out = (uint8_t)((lfl << 4) | rfl);
-            gr.insert_straight(st);
+            gr.insert_straight(std::move(st));
         }
     }
 }
@@ -471,7 +471,7 @@ void make_initial_from_nodes(Graph<W> &gr, NodeSet<W> &nd, const ChainRecords &c
         st.seq.resize((len + k + 31) / 32, 0);                // binstr_t(length + k) word count (graph.h:559)
         st.coverage = (u16)(static_cast<double>(cs.sum[c]) / static_cast<double>(len) + 0.5);
         st.out = (uint8_t)((lfl << 4) | rfl);
-        gr.insert_straight(st);
+        gr.insert_straight(std::move(st));
     };
     auto run_stack = [&]() {
         while (!stack.empty()) {
@@ -552,7 +552,7 @@ void make_initial_from_nodes(Graph<W> &gr, NodeSet<W> &nd, const ChainRecords &c
             for (u64 j = 0; j < lseq.size(); ++j) st.set(rn + k + j, lseq[j]);
             st.coverage = (u16)(static_cast<double>(sum) / static_cast<double>(st.length) + 0.5);
             st.out = (uint8_t)((lfl << 4) | rfl);
-            gr.insert_straight(st);
+            gr.insert_straight(std::move(st));
         }
     };
     u64 pn = 0, pc = 0;

@@ -40,6 +40,7 @@ struct Straight {
     u64 length = 0;               // number of k-mers; sequence length = length + k - 1
     u16 coverage = 0;
     uint8_t out = 0;              // (left one-hot << 4) | right one-hot
+    mutable uint32_t export_id = 0;   // clean_pass_device: 1 + index of the node in the arrays it sends to the device (0: not sent); no meaning elsewhere
     std::vector<u64> seq;
     unsigned get(u64 pos) const { return (unsigned)((seq[pos / 32] >> ((pos % 32) * 2)) & 3); }
     void set(u64 pos, unsigned v)
@@ -189,8 +190,16 @@ struct Graph {
     void insert_straight(const Straight &s)                                             // graph.h:809-821
     {
         const K h = head_of(s), t = tail_of(s);
-        left[h] = s;
-        right[t] = &left[h];
+        Straight &dst = left[h];
+        dst = s;
+        right[t] = &dst;
+    }
+    void insert_straight(Straight &&s)                                                  // (the same insertions in the same order; the sequence is moved, not copied)
+    {
+        const K h = head_of(s), t = tail_of(s);
+        Straight &dst = left[h];
+        dst = std::move(s);
+        right[t] = &dst;
     }
 
     u64 estimate_kmers_on_straight() const              // graph.h:245-254
@@ -343,12 +352,18 @@ struct Graph {
         std::vector<u16> cov, jcov;
         std::vector<uint8_t> out, jout, dec;
         std::vector<uint32_t> tids;
-        std::unordered_map<const Straight *, uint32_t> id_of;
         std::vector<typename std::unordered_map<K, Straight, KeyHash<W>>::iterator> its;
+        {
+            const size_t n0 = left.size();                            // (at 100 Mbp a pass exports a million nodes: no regrowth, no pointer-keyed map)
+            head.reserve(n0 * W); tail.reserve(n0 * W); len.reserve(n0); cov.reserve(n0); out.reserve(n0); its.reserve(n0);
+            tkeys.reserve(right.size() * W); tids.reserve(right.size());
+            jkeys.reserve(junctions.size() * W); jcov.reserve(junctions.size()); jout.reserve(junctions.size());
+        }
         for (auto it = left.begin(), end = left.end(); it != end; ++it) {
             const Straight &st = it->second;
+            st.export_id = 0;
             if (st.coverage == 65535) continue;
-            id_of[&st] = (uint32_t)its.size();
+            st.export_id = (uint32_t)its.size() + 1;
             its.push_back(it);
             const K t = tail_of(st);
             for (int w = 0; w < W; ++w) { head.push_back(it->first.w[w]); tail.push_back(t.w[w]); }
@@ -358,11 +373,9 @@ struct Graph {
         }
         if (its.empty()) return false;
         for (auto &e : right) {                                       // rightStraightTable as it stands (an entry may point to a straight with another tail)
-            if (e.second->coverage == 65535) continue;
-            auto f = id_of.find(e.second);
-            if (f == id_of.end()) continue;
+            if (e.second->coverage == 65535 || e.second->export_id == 0) continue;
             for (int w = 0; w < W; ++w) tkeys.push_back(e.first.w[w]);
-            tids.push_back(f->second);
+            tids.push_back(e.second->export_id - 1);
         }
         for (auto &e : junctions) {
             if (e.second.coverage == 65535) continue;
