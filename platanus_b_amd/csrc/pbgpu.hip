@@ -139,6 +139,8 @@ struct pb_ctx {
     u64 sk_flagged = 0, sk_spilled = 0, sk_extra_for = 0;
     u64 sk_fcap = 0, sk_fcap_for = 0;   // capacity of the fallback table that an earlier pass over the same stream needed
     u64 sk_room6_for = 0;               // ... and the stream (by its window count) whose buckets needed 6 x the mean as capacity
+    u64 sk_out_need = 0, sk_out_for = 0;   // ... and the distinct keys of a stream whose output arrays, sized by estimate, were too small
+    int opt_out_div = 0;                // "sk_out_div" (tests): the output arrays of the k <= 32 pass are sized for windows / value keys whatever the input size
     u64 hist_done = 0;              // leading records of the distinct arrays already tallied into d_hist
     unsigned sk_bits = 0, sk_extra_bits = 0;       // bucket bits used; extra bits that an earlier pass over the same stream needed
     // pb_set_option: choices between equivalent implementations (tests and A/B runs; no option changes a result)
@@ -349,6 +351,7 @@ static int *option_slot(pb_ctx *ctx, const std::string &n, long value)
     if (n == "sk_bucket_form" && (value == 1 || value == 2)) return &ctx->opt_bucket_form;
     if (n == "sk_bucket_blocks" && value >= 0 && value <= 65536) return &ctx->opt_bucket_blocks;
     if (n == "hist_zeroed" && (value == 0 || value == 1)) return &ctx->opt_hist_zeroed;
+    if (n == "sk_out_div" && value >= 0 && value <= (1 << 20)) return &ctx->opt_out_div;
     return nullptr;
 }
 
@@ -685,8 +688,17 @@ static int count_superk(pb_ctx *ctx, unsigned k, bool *done, bool want_pos = fal
         p.cursor1 = (u32 *)ctx->part_meta.p;
         p.cursor2 = p.cursor1 + nb1 * SK_CUR1_STRIDE;
         p.flag2 = p.cursor2 + nb2;
-        // the distinct arrays are written in place: room for every bucket's table full, plus the fallback table's records
-        const u64 out_cap = std::min<u64>(std::max<u64>(ctx->stream_len, 1), nb2 * (u64)SK_SLOT_LIMIT);
+        // the distinct arrays are written in place: room for every bucket's table full, plus the fallback table's records.  For a large input
+        // that bound is tens of GB that are never written (100 Mbp x 100x: 48 GB for 1.2 G keys of 7.9 G windows) and device memory costs
+        // ~30 ms per GB to get: then the arrays are sized for windows / 5 keys (sequencing depth gives ~ windows / 6.5); a pass that finds
+        // more says how many (scalars[4] counts on) and is repeated once with exactly that.
+        const u64 out_bound = std::min<u64>(std::max<u64>(ctx->stream_len, 1), nb2 * (u64)SK_SLOT_LIMIT);
+        u64 out_cap = out_bound;
+        {
+            const u64 div = ctx->opt_out_div ? (u64)ctx->opt_out_div : (out_bound * 12 > (8ull << 30) ? 5 : 0);
+            if (ctx->sk_out_need && ctx->sk_out_for == windows) out_cap = std::min(out_bound, ctx->sk_out_need);
+            else if (div) out_cap = std::min(out_bound, std::max<u64>(windows / div, 1ull << 12));
+        }
         if ((rc = ensure(ctx, ctx->dist_keys, (out_cap + fcap) * 8)) != PB_OK) return rc;
         if ((rc = ensure(ctx, ctx->dist_counts, (out_cap + fcap) * 4)) != PB_OK) return rc;
         if (want_pos && (rc = ensure(ctx, ctx->sk_first, (out_cap + fcap) * 4)) != PB_OK) return rc;
@@ -850,6 +862,11 @@ static int count_superk(pb_ctx *ctx, unsigned k, bool *done, bool want_pos = fal
             continue;
         }
         if (!forced_b && sc[7] > nb2 / 4) return PB_OK;            // still mostly overflowing at 2^20 buckets: the direct path takes it
+        if (sc[4] > out_cap && out_cap < out_bound) {              // the estimate above was too small: once more, with what this pass counted
+            ctx->sk_out_need = sc[4];
+            ctx->sk_out_for = windows;
+            continue;
+        }
         ctx->stage_ms["seg_compact"] = 0.f;
         const bool all_in_lds = sc[7] + sc[8] == 0;                // then h_hist already holds the whole histogram
         if (want_pos && !all_in_lds) return PB_OK;                 // records that left the LDS path carry no position: the caller takes the probing kernel

@@ -101,11 +101,36 @@ struct Driver {
             return true;
         };
     }
+    // The node tables of a finished round are emptied (millions of nodes freed one by one: a second per round at 100 Mbp) by a helper thread
+    // beside the device stages of the next round; joined before the next replay touches a graph.
+    std::thread bg;
+    double bg_s = 0;
+    std::exception_ptr bg_err;
+    template <typename F> void background(F f)
+    {
+        join_background();
+        bg = std::thread([this, f]() {
+            const auto t0 = std::chrono::steady_clock::now();
+            try { f(); } catch (...) { bg_err = std::current_exception(); }
+            bg_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        });
+    }
+    void join_background()
+    {
+        if (!bg.joinable()) return;
+        {
+            Tick t("wait for the graph reset (host)");
+            bg.join();
+        }
+        g_clock.add("graph reset (host thread, beside the device stages)", bg_s);
+        if (bg_err) { std::exception_ptr e = bg_err; bg_err = nullptr; std::rethrow_exception(e); }
+    }
     bool dist() const { return opt.world > 1; }    // N ranks on this run: the table is merged over them before every graph stage
     bool writer() const { return opt.rank == 0; }  // every rank computes the same graph; rank 0 writes the files
     ~Driver()
     {
         if (creator.joinable()) creator.join();
+        if (bg.joinable()) bg.join();
         pb_destroy(ctx);
     }
     void chk(int rc) const { if (rc != PB_OK) throw GpuError(rc, std::string("libpbgpu: ") + pb_last_error(ctx)); }
@@ -139,11 +164,13 @@ struct Driver {
             graph_from_device<W>(ctx, g, kk, [this](int rc) { chk(rc); }, [&](const char *stage) {
                 if (!strncmp(stage, "adjacency", 9)) log("connecting kmers...");
                 t.reset();
+                if (!strncmp(stage, "DFS", 3)) join_background();      // the replay starts with the tables of this width
                 t.reset(new Tick(stage));
             });
             return;
         }
         // development / A-B: the full per-k-mer arrays on the host (PB_GRAPH_FETCH=full, PB_NO_CHAINS=1 for the k-mer-level replay)
+        join_background();
         {
             Tick t("fetch retained + adjacency (device + D2H)");
             keys.resize(n * W); counts.resize(n); adj.resize(n); nbr.resize(2 * n);
@@ -321,33 +348,45 @@ struct Driver {
         fclose(f);
     }
 
-    // assemble.cpp:449-459 saveGraph: edge k-mers of the finished graph -> read filter on the device
-    template <int W> void save_graph(unsigned graph_k, unsigned next_k)
-    {
-        std::vector<u64> edge;
-        Tick t0("edge k-mers (host)");
-        graph<W>().save_edge_kmers([&](const Key<W> &key, u16) { for (int w = 0; w < W; ++w) edge.push_back(key.w[w]); }, next_k);
-        log("extracting reads (containing kmer used in contig assemble)...");
-        u64 kept = 0;
-        t0.stop();
-        Tick t("read filter (device)");
-        chk(pb_reads_filter(ctx, graph_k, edge.data(), edge.size() / W, &kept));
-    }
-
-    // saveContig<NEXT> (graph.h:1655-1771): strings + values go to the device, which derives the next-k table
-    template <int WP> void contig_table(unsigned next_k, double ratio)
+    // assemble.cpp:449-459 saveGraph (edge k-mers of the finished graph -> read filter on the device) and saveContig<NEXT> (graph.h:1655-1771:
+    // strings + values go to the device, which derives the next-k table).  Both only read the graph: the strings are collected by a helper
+    // thread while this one lists the edge k-mers and the device filters the reads.
+    template <int W> void save_graph_and_contig_table(unsigned graph_k, unsigned next_k, double ratio)
     {
         std::vector<uint8_t> bases;
         std::vector<u64> off{0};
         std::vector<u16> vals;
-        Tick t0("contig strings (host)");
-        graph<WP>().for_each_contig_string(next_k, ratio, [&](const std::vector<unsigned char> &str, u16 occ) {
-            bases.insert(bases.end(), str.begin(), str.end());
-            off.push_back(bases.size());
-            vals.push_back(occ);
+        double strings_s = 0;
+        std::exception_ptr err;
+        struct Joiner { std::thread t; ~Joiner() { if (t.joinable()) t.join(); } } strings;
+        strings.t = std::thread([&]() {
+            const auto t0 = std::chrono::steady_clock::now();
+            try {
+                graph<W>().for_each_contig_string(next_k, ratio, [&](const std::vector<unsigned char> &str, u16 occ) {
+                    bases.insert(bases.end(), str.begin(), str.end());
+                    off.push_back(bases.size());
+                    vals.push_back(occ);
+                });
+            } catch (...) { err = std::current_exception(); }
+            strings_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         });
+        {
+            std::vector<u64> edge;
+            Tick t0("edge k-mers (host)");
+            graph<W>().save_edge_kmers([&](const Key<W> &key, u16) { for (int w = 0; w < W; ++w) edge.push_back(key.w[w]); }, next_k);
+            log("extracting reads (containing kmer used in contig assemble)...");
+            u64 kept = 0;
+            t0.stop();
+            Tick t("read filter (device)");
+            chk(pb_reads_filter(ctx, graph_k, edge.data(), edge.size() / W, &kept));
+        }
+        {
+            Tick t("wait for the contig strings (host)");
+            strings.t.join();
+        }
+        g_clock.add("contig strings (host thread, beside edge k-mers + read filter)", strings_s);
+        if (err) std::rethrow_exception(err);
         u64 nw = 0;
-        t0.stop();
         Tick t("contig table (device)");
         chk(pb_contig_table_build(ctx, next_k, bases.data(), off.data(), vals.data(), vals.size(), &nw));
     }
@@ -371,12 +410,8 @@ struct Driver {
     // assemble.cpp:392-443
     template <int WP, int WN> void save_and_redo(unsigned kk, unsigned prev_k, u64 position)
     {
-        save_graph<WP>(prev_k, kk);
-        contig_table<WP>(kk, (avg_len - kk + 1.0) / (avg_len - prev_k + 1.0));
-        {
-            Tick t("graph reset (host)");
-            graph<WP>().delete_all();
-        }
+        save_graph_and_contig_table<WP>(prev_k, kk, (avg_len - kk + 1.0) / (avg_len - prev_k + 1.0));
+        background([this]() { graph<WP>().delete_all(); });
         if (opt.verbose) std::cerr << "K = " << kk << ", loading kmers from contigs..." << std::endl;
         redo<WN>(kk, position);
     }
@@ -403,12 +438,8 @@ struct Driver {
         }
         // saveGraph(k, allReadFP): diff == 0, so no edge k-mer is stored and no read survives
         chk(pb_reads_restore(ctx));
-        save_graph<W>(kk, kk);
-        contig_table<W>(kk, 1.0);
-        {
-            Tick t("graph reset (host)");
-            g.delete_all();
-        }
+        save_graph_and_contig_table<W>(kk, kk, 1.0);
+        background([&g]() { g.delete_all(); });
         if (opt.verbose) std::cerr << "K = " << kk << ", loading kmers from contigs..." << std::endl;
         if (opt.verbose) std::cerr << "K = " << kk << ", saving additional kmers(not found in contigs) from reads..." << std::endl;
         u64 nd = 0;

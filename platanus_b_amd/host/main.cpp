@@ -11,6 +11,7 @@
 #include <csignal>
 #include <execinfo.h>
 #include <sys/mman.h>
+#include <sys/time.h>
 #include <sys/wait.h>
 #include <unistd.h>
 
@@ -173,9 +174,61 @@ static void install_crash_trace()
     for (int sig : {SIGSEGV, SIGBUS, SIGFPE, SIGILL, SIGABRT}) sigaction(sig, &sa, nullptr);
 }
 
+// Development: PB_HOST_SAMPLES=FILE -> the process's CPU time is sampled (SIGPROF every millisecond, a few return addresses per sample) and
+// the raw addresses go to FILE with /proc/self/maps at exit; tools/host_samples.py turns that into a profile by function (there is no perf
+// on the boxes, and gprof does not see libc / libstdc++).
+static const int SAMPLE_DEPTH = 8;
+static void **g_samples = nullptr;
+static volatile long g_n_samples = 0;
+static const long SAMPLE_CAP = 1L << 21;
+static const char *g_samples_path = nullptr;
+static void sample_tick(int)
+{
+    const long at = __sync_fetch_and_add(&g_n_samples, 1);
+    if (at >= SAMPLE_CAP) return;
+    void *fr[SAMPLE_DEPTH + 2];
+    const int n = backtrace(fr, SAMPLE_DEPTH + 2);
+    for (int i = 0; i < SAMPLE_DEPTH; ++i) g_samples[at * SAMPLE_DEPTH + i] = i + 2 < n ? fr[i + 2] : nullptr;      // (without the handler and the signal frame)
+}
+static void samples_write()
+{
+    struct itimerval off;
+    memset(&off, 0, sizeof(off));
+    setitimer(ITIMER_PROF, &off, nullptr);
+    FILE *f = fopen(g_samples_path, "w");
+    if (!f) return;
+    if (FILE *m = fopen("/proc/self/maps", "r")) { char ln[1024]; while (fgets(ln, sizeof ln, m)) fputs(ln, f); fclose(m); }
+    fputs("#### SAMPLES ####\n", f);
+    const long n = g_n_samples < SAMPLE_CAP ? g_n_samples : SAMPLE_CAP;
+    for (long i = 0; i < n; ++i) {
+        for (int j = 0; j < SAMPLE_DEPTH; ++j) fprintf(f, j ? " %lx" : "%lx", (unsigned long)(uintptr_t)g_samples[i * SAMPLE_DEPTH + j]);
+        fputc('\n', f);
+    }
+    fclose(f);
+}
+static void install_host_sampler()
+{
+    g_samples_path = getenv("PB_HOST_SAMPLES");
+    if (!g_samples_path || !*g_samples_path) return;
+    g_samples = (void **)calloc((size_t)SAMPLE_CAP * SAMPLE_DEPTH, sizeof(void *));
+    if (!g_samples) return;
+    struct sigaction sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.sa_handler = sample_tick;
+    sa.sa_flags = SA_RESTART;
+    sigemptyset(&sa.sa_mask);
+    sigaction(SIGPROF, &sa, nullptr);
+    atexit(samples_write);
+    struct itimerval it;
+    it.it_interval.tv_sec = 0; it.it_interval.tv_usec = 1000;
+    it.it_value = it.it_interval;
+    setitimer(ITIMER_PROF, &it, nullptr);
+}
+
 int main(int argc, char **argv)
 {
     install_crash_trace();
+    install_host_sampler();
     show_version_and_args(argc, argv);
     if (argc >= 2 && strcmp(argv[1], "-v") == 0) return 0;                       // main.cpp:77-79
     if (argc >= 2 && strcmp(argv[1], "kmer_divide") == 0) return main_kmer_divide(argc, argv);

@@ -24,6 +24,8 @@
 #include <unordered_map>
 #include <functional>
 #include <map>
+#include <thread>
+#include <exception>
 #include <vector>
 
 namespace pbh {
@@ -167,8 +169,25 @@ struct Graph {
     K succ(const K &s, unsigned b) const { K r = s; r.shl2(k); r.set(0, b); return r; }
     K pred(const K &s, unsigned b) const { K r = s; r.shr2(); r.set(k - 1, b); return r; }
     K canon(const K &s) const { K r = revcomp(s, k); return r < s ? r : s; }
-    K head_of(const Straight &s) const { K r; for (unsigned i = 0; i < k; ++i) r.set(i, s.get(s.length + i - 1)); return r; }
-    K tail_of(const Straight &s) const { K r; for (unsigned i = 0; i < k; ++i) r.set(i, s.get(i)); return r; }
+    // the k bases at positions at .. at + k - 1 of a node's sequence as a key (key position j = sequence position at + j): word shifts, not k
+    // get / set pairs (a key and a sequence have the same bit layout; r3: the node tables of a 100 Mbp genome ask for millions of these per pass)
+    K key_at(const Straight &s, u64 at) const
+    {
+        K r;
+        const u64 ws = at >> 5, sz = s.seq.size();
+        const unsigned bs = (unsigned)(at & 31) * 2;
+        const int n = words_for_k(k);
+        for (int i = 0; i < n; ++i) {
+            const u64 lo = ws + i < sz ? s.seq[ws + i] : 0, hi = (bs && ws + i + 1 < sz) ? s.seq[ws + i + 1] : 0;
+            r.w[i] = bs ? (lo >> bs) | (hi << (64 - bs)) : lo;
+        }
+        r.mask(k);
+        return r;
+    }
+    K head_of(const Straight &s) const { return key_at(s, s.length - 1); }
+    K tail_of(const Straight &s) const { return key_at(s, 0); }
+    // the k-mer that follows a node's tail on base b: bases 0 .. k-2 of the node at key positions 1 .. k-1, b at position 0
+    K right_of_tail(const Straight &s, unsigned b) const { K r = key_at(s, 0); r.shl2(k); r.set(0, b); return r; }
 
     Straight *find_head(const K &key)                  // graph.h:194-201
     {
@@ -353,35 +372,68 @@ struct Graph {
         std::vector<uint8_t> out, jout, dec;
         std::vector<uint32_t> tids;
         std::vector<typename std::unordered_map<K, Straight, KeyHash<W>>::iterator> its;
+        std::vector<const Straight *> tptr;
         {
             const size_t n0 = left.size();                            // (at 100 Mbp a pass exports a million nodes: no regrowth, no pointer-keyed map)
             head.reserve(n0 * W); tail.reserve(n0 * W); len.reserve(n0); cov.reserve(n0); out.reserve(n0); its.reserve(n0);
-            tkeys.reserve(right.size() * W); tids.reserve(right.size());
+            tkeys.reserve(right.size() * W); tptr.reserve(right.size());
             jkeys.reserve(junctions.size() * W); jcov.reserve(junctions.size()); jout.reserve(junctions.size());
         }
-        for (auto it = left.begin(), end = left.end(); it != end; ++it) {
-            const Straight &st = it->second;
-            st.export_id = 0;
-            if (st.coverage == 65535) continue;
-            st.export_id = (uint32_t)its.size() + 1;
-            its.push_back(it);
-            const K t = tail_of(st);
-            for (int w = 0; w < W; ++w) { head.push_back(it->first.w[w]); tail.push_back(t.w[w]); }
-            len.push_back(st.length);
-            cov.push_back(st.coverage);
-            out.push_back(st.out);
+        // the three tables are walked in container order, each by itself: on large graphs by three threads (a walk is one cache miss per
+        // node and nothing else: r3, 100 Mbp -- a tenth of the whole run was this function)
+        auto walk_left = [&]() {
+            for (auto it = left.begin(), end = left.end(); it != end; ++it) {
+                const Straight &st = it->second;
+                st.export_id = 0;
+                if (st.coverage == 65535) continue;
+                st.export_id = (uint32_t)its.size() + 1;
+                its.push_back(it);
+                const K t = tail_of(st);
+                for (int w = 0; w < W; ++w) { head.push_back(it->first.w[w]); tail.push_back(t.w[w]); }
+                len.push_back(st.length);
+                cov.push_back(st.coverage);
+                out.push_back(st.out);
+            }
+        };
+        auto walk_right = [&]() {                                     // rightStraightTable as it stands (an entry may point to a straight with another tail)
+            for (auto &e : right) {
+                if (e.second->coverage == 65535) continue;
+                for (int w = 0; w < W; ++w) tkeys.push_back(e.first.w[w]);
+                tptr.push_back(e.second);
+            }
+        };
+        auto walk_junctions = [&]() {
+            for (auto &e : junctions) {
+                if (e.second.coverage == 65535) continue;
+                for (int w = 0; w < W; ++w) jkeys.push_back(e.first.w[w]);
+                jcov.push_back(e.second.coverage);
+                jout.push_back(e.second.out);
+            }
+        };
+        if (left.size() + right.size() + junctions.size() >= (1u << 16)) {
+            std::exception_ptr err[2];
+            std::thread tr([&]() { try { walk_right(); } catch (...) { err[0] = std::current_exception(); } });
+            std::thread tj([&]() { try { walk_junctions(); } catch (...) { err[1] = std::current_exception(); } });
+            try { walk_left(); } catch (...) { tr.join(); tj.join(); throw; }
+            tr.join();
+            tj.join();
+            for (auto &e : err) if (e) std::rethrow_exception(e);
+        } else {
+            walk_left();
+            walk_right();
+            walk_junctions();
         }
         if (its.empty()) return false;
-        for (auto &e : right) {                                       // rightStraightTable as it stands (an entry may point to a straight with another tail)
-            if (e.second->coverage == 65535 || e.second->export_id == 0) continue;
-            for (int w = 0; w < W; ++w) tkeys.push_back(e.first.w[w]);
-            tids.push_back(e.second->export_id - 1);
-        }
-        for (auto &e : junctions) {
-            if (e.second.coverage == 65535) continue;
-            for (int w = 0; w < W; ++w) jkeys.push_back(e.first.w[w]);
-            jcov.push_back(e.second.coverage);
-            jout.push_back(e.second.out);
+        tids.resize(tptr.size());                                     // (the export ids are the left walk's: read after both walks are done)
+        {
+            size_t o = 0;
+            for (size_t i = 0; i < tptr.size(); ++i) {
+                if (tptr[i]->export_id == 0) continue;                // (a live straight that the left table does not hold: cannot happen)
+                if (o != i) for (int w = 0; w < W; ++w) tkeys[o * W + w] = tkeys[i * W + w];
+                tids[o++] = tptr[i]->export_id - 1;
+            }
+            tids.resize(o);
+            tkeys.resize(o * W);
         }
         dec.assign(its.size(), 0);
         if (!clean_decide(k, its.size(), head.data(), tail.data(), len.data(), cov.data(), out.data(), tids.size(), tkeys.data(), tids.data(), jcov.size(),
@@ -396,9 +448,7 @@ struct Graph {
                 if (!jn) throw std::runtime_error("cutBranch: the device marked a tip whose junction is not in the junction table");
                 jn->out ^= 1u << st->get(st->length - 1);
             } else {
-                K jk;
-                for (unsigned j = 1; j < k; ++j) jk.set(j, st->get(j - 1));
-                jk.set(0, flag2base(st->out & 0xf));
+                const K jk = right_of_tail(*st, flag2base(st->out & 0xf));
                 Junction *jn = find_junction(jk);
                 if (!jn) throw std::runtime_error("cutBranch: the device marked a tip whose junction is not in the junction table");
                 jn->out ^= 1u << (4 + st->get(k - 1));
@@ -414,10 +464,7 @@ struct Graph {
                 if (jn) jn->out ^= 1u << st.get(st.length - 1);
             }
             if (st.out & 0xf) {
-                K key;
-                for (unsigned j = 0; j < k - 1; ++j) key.set(j + 1, st.get(j));
-                key.set(0, flag2base(st.out & 0xf));
-                Junction *jn = find_junction(key);
+                Junction *jn = find_junction(right_of_tail(st, flag2base(st.out & 0xf)));
                 if (jn) jn->out ^= 1u << (4 + st.get(k - 1));
             }
             delete_straight(st);
@@ -454,9 +501,7 @@ struct Graph {
                 if (st->coverage > max_cov * branch_th) continue;
                 jn->out ^= 1u << st->get(st->length - 1);
             } else if (st->out & 0xf) {
-                K jk;
-                for (unsigned j = 1; j < k; ++j) jk.set(j, st->get(j - 1));
-                jk.set(0, flag2base(st->out & 0xf));
+                const K jk = right_of_tail(*st, flag2base(st->out & 0xf));
                 Junction *jn = find_junction(jk);
                 if (!jn) continue;
                 u64 max_cov = 0;
@@ -567,8 +612,7 @@ struct Graph {
             ls = &fresh;
 
             if (flag_count(ls->out & 0xf)) {
-                for (unsigned j = 0; j < k - 1; ++j) key.set(j + 1, ls->get(j));
-                key.set(0, flag2base(ls->out & 0xf));
+                key = right_of_tail(*ls, flag2base(ls->out & 0xf));
                 rs = find_head(key);
                 if (rs == nullptr) {
                     rj = find_junction(key);
@@ -590,9 +634,7 @@ struct Graph {
                 st = &merged;
             }
             if (flag_count(st->out & 0xf)) {
-                K key;
-                for (unsigned j = 1; j < k; ++j) key.set(j, st->get(j - 1));
-                key.set(0, flag2base(st->out & 0xf));
+                const K key = right_of_tail(*st, flag2base(st->out & 0xf));
                 Straight *rs = find_head(key);
                 if (rs != nullptr) concat_ss(st, rs);
             }
@@ -624,10 +666,7 @@ struct Graph {
                 if (jn) jn->out ^= 1u << st.get(st.length - 1);
             }
             if (st.out & 0xf) {
-                K key;
-                for (unsigned i = 0; i < k - 1; ++i) key.set(i + 1, st.get(i));
-                key.set(0, flag2base(st.out & 0xf));
-                Junction *jn = find_junction(key);
+                Junction *jn = find_junction(right_of_tail(st, flag2base(st.out & 0xf)));
                 if (jn) jn->out ^= 1u << (4 + st.get(k - 1));
             }
             delete_straight(st);
@@ -660,10 +699,7 @@ struct Graph {
             if (!(root->out & (1u << b))) continue;
             st[b] = find_head(succ(root_key, b));
             if (st[b] != nullptr && (st[b]->out & 0x0f)) {
-                K key;
-                for (unsigned j = 0; j < k - 1; ++j) key.set(j + 1, st[b]->get(j));
-                key.set(0, flag2base(st[b]->out & 0x0f));
-                jn[b] = find_junction(key);
+                jn[b] = find_junction(right_of_tail(*st[b], flag2base(st[b]->out & 0x0f)));
             }
         }
     }
@@ -859,11 +895,12 @@ struct Graph {
             const Straight &st = e.second;
             if (st.coverage == 65535) continue;
             auto emit_run = [&](u64 first_pos, u64 count) {
-                // k-mers whose 3' bases are at positions first_pos, first_pos-1, ... (count of them)
+                // k-mers whose 3' bases are at positions first_pos, first_pos-1, ... (count of them): the first one is taken out of the
+                // sequence whole, the others are rolled
                 Kmer<W> km(k);
-                for (unsigned i = 0; i < k - 1; ++i) km.push_right(st.get(first_pos + k - 1 - i));
+                km.set_forward(key_at(st, first_pos));
                 for (u64 i = 0; i < count; ++i) {
-                    km.push_right(st.get(first_pos - i));
+                    if (i) km.push_right(st.get(first_pos - i));
                     if (st.coverage != 0) put(km.canon(), st.coverage);
                 }
             };
@@ -873,14 +910,12 @@ struct Graph {
                 // the reference interleaves left and right inserts (graph.h:1919-1935); slot layout of this
                 // scratch table is never observed, only membership, so the two runs are emitted in turn here too
                 Kmer<W> lk(k), rk(k);
-                for (unsigned i = 0; i < k - 1; ++i) {
-                    lk.push_right(st.get(st.length + k - 2 - i));
-                    rk.push_right(st.get(k + diff - 2 - i));
-                }
+                lk.set_forward(key_at(st, st.length - 1));
+                rk.set_forward(key_at(st, diff - 1));
                 for (unsigned i = 0; i < diff; ++i) {
-                    lk.push_right(st.get(st.length - 1 - i));
+                    if (i) lk.push_right(st.get(st.length - 1 - i));
                     if (st.coverage != 0) put(lk.canon(), st.coverage);
-                    rk.push_right(st.get(diff - 1 - i));
+                    if (i) rk.push_right(st.get(diff - 1 - i));
                     if (st.coverage != 0) put(rk.canon(), st.coverage);
                 }
             }
@@ -916,9 +951,7 @@ struct Graph {
             }
             st->append_bases(str, st->length + k - 1);
             if (st->out & 0xf) {
-                K jk;
-                for (unsigned i = 1; i < k; ++i) jk.set(i, st->get(i - 1));
-                jk.set(0, flag2base(st->out & 0xf));
+                const K jk = right_of_tail(*st, flag2base(st->out & 0xf));
                 Junction *jn = find_junction(jk);
                 if (jn != nullptr) {
                     str.push_back(jk.get(0));

@@ -764,6 +764,19 @@ def test_superkmer_both_forms_of_the_bucket_kernel(form, bits, gpu, oracle_built
     _superk_case(gpu, oracle_built, np.concatenate([r1, r2]), 27, cutoffs=(2,))
 
 
+@pytest.mark.parametrize("div", [3, 1000000])
+def test_superkmer_output_arrays_sized_by_estimate(div, gpu, oracle_built, monkeypatch):
+    """r3: for large inputs the (key, count) arrays of the k <= 32 pass are sized for windows / 5 keys instead of one per window (device memory
+    costs ~30 ms per GB); a pass that finds more distinct keys than that is repeated once with the number it counted.  `sk_out_div` applies
+    the rule to a small input: windows / 3 does not hold a 20x set with 1 % errors, windows / 10^6 holds nothing -- same results as ever."""
+    from platanus_b_amd import synth
+    monkeypatch.setitem(GpuCounter.default_options, "count_path", COUNT_PATH["superk"])
+    monkeypatch.setitem(GpuCounter.default_options, "sk_out_div", div)
+    r1, r2 = synth.make_reads(120_000, 20, seed=41, err=0.01, n_rate=0.001)
+    _superk_case(gpu, oracle_built, np.concatenate([r1, r2]), 32, cutoffs=(1, 2))
+    _superk_case(gpu, oracle_built, np.concatenate([r1, r2]), 21, cutoffs=(2,))
+
+
 def test_counting_pass_replayed_as_a_graph(gpu, oracle_built, monkeypatch):
     """r3: the k <= 32 pass is captured on its first run over a set of buffers and replayed as one graph launch afterwards; a replay must
     give what the kernel-by-kernel pass gives (histogram head copied out with the scalars, tail fetched only when counts reach beyond it --
