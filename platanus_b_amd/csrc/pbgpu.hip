@@ -985,7 +985,8 @@ static int count_superk2(pb_ctx *ctx, unsigned k, bool *done)
             const u64 n_tiles = (ctx->stream_len + SK2_OWN - 1) / SK2_OWN;
             const size_t dig_bytes = (size_t)2 * 4 * (1u << p.l1);
             const u64 nw64 = (ctx->stream_len + 63) / 64 + PB_STREAM_PAD_WORDS64;
-            sk2_part1_kernel<<<grid_for(n_tiles, 1, 256 * 16), SK1_THREADS, dig_bytes, ctx->stream>>>((const u64 *)ctx->packed.p, cur_mask(ctx), ctx->stream_len, nw64, p);
+            if (p.m <= 32) sk2_part1_kernel<true><<<grid_for(n_tiles, 1, 256 * 16), SK1_THREADS, dig_bytes, ctx->stream>>>((const u64 *)ctx->packed.p, cur_mask(ctx), ctx->stream_len, nw64, p);
+            else sk2_part1_kernel<false><<<grid_for(n_tiles, 1, 256 * 16), SK1_THREADS, dig_bytes, ctx->stream>>>((const u64 *)ctx->packed.p, cur_mask(ctx), ctx->stream_len, nw64, p);
             t1.stop();
             LazyTimer t2(ctx, "part2", 1);
             const u64 exp_tiles = (u64)(est_rec / (double)nb1) / SK2P_RCAP + 1;
@@ -993,7 +994,8 @@ static int count_superk2(pb_ctx *ctx, unsigned k, bool *done)
             sk2_part2_kernel<<<dim3(blocks_per_sub, (unsigned)nb1), SK_THREADS, 0, ctx->stream>>>(p);
             t2.stop();
             LazyTimer t3(ctx, "bucket", 2);
-            sk2_bucket_kernel<<<grid_for(nb2, 1, 256 * 16), SK2_BUCKET_THREADS, 0, ctx->stream>>>(p, (u64 *)ctx->dist_keys.p, (u32 *)ctx->dist_counts.p, out_cap);
+            if (ctx->opt_bucket_form == 2) sk2_bucket2_kernel<<<grid_for(nb2, 1, ctx->opt_bucket_blocks ? (unsigned)ctx->opt_bucket_blocks : 256 * 16), SK2_BUCKET_THREADS, 0, ctx->stream>>>(p, (u64 *)ctx->dist_keys.p, (u32 *)ctx->dist_counts.p, out_cap);
+            else sk2_bucket_kernel<<<grid_for(nb2, 1, 256 * 16), SK2_BUCKET_THREADS, 0, ctx->stream>>>(p, (u64 *)ctx->dist_keys.p, (u32 *)ctx->dist_counts.p, out_cap);
             t3.stop();
             HIPCHK(hipGetLastError());
             HIPCHK(hipMemcpyAsync(sc, ctx->d_scalars.p, 72, hipMemcpyDeviceToHost, ctx->stream));

@@ -523,6 +523,25 @@ def test_superkmer_two_word_keys(k, gpu, oracle_built, monkeypatch):
     _superk_case(gpu, oracle_built, np.concatenate([r1, r2]), k)
 
 
+@pytest.mark.parametrize("form", [1, 2])
+@pytest.mark.parametrize("bits,k", [(3, 45), (9, 33), (12, 64), (12, 48)])
+def test_superkmer_two_word_keys_both_forms_of_the_bucket_kernel(form, bits, k, gpu, oracle_built, monkeypatch):
+    """r3: sk2_bucket2_kernel (whole bucket per round, block-wide piece list, two home slots + parked keys, rolled reverse key: the default)
+    and sk2_bucket_kernel (chunks, per-wave piece lists, claim loops) against the oracle.  With 8 buckets the record table of either form is
+    far too small (the second form then puts windows straight into the table of keys, on the slot sequence the pieces use) and the tables of
+    keys overflow: those buckets go through the global table.  Poly-T / poly-A reads bring keys whose low word is all ones (the second
+    form's empty mark: their buckets are flagged)."""
+    from platanus_b_amd import synth
+    monkeypatch.setitem(GpuCounter.default_options, "count_path", COUNT_PATH["superk"])
+    monkeypatch.setitem(GpuCounter.default_options, "sk_bucket_bits", bits)
+    monkeypatch.setitem(GpuCounter.default_options, "sk_bucket_form", form)
+    r1, r2 = synth.make_reads(70_000, 50, seed=500 + bits + k, err=0.01, n_rate=0.001)
+    poly = np.full((40, r1.shape[1]), 3, dtype=np.uint8)
+    poly[:20] = 0
+    poly[::3, 70] = 1                                        # (some of them broken by one other base)
+    _superk_case(gpu, oracle_built, np.concatenate([r1, poly, r2]), k, cutoffs=(1, 3), must_take_path=False)
+
+
 def test_dist_rccl_calls_with_the_rank_as_its_own_peer(gpu):
     """csrc/dist.inc talks to RCCL through dlopen (no link-time dependency): symbols, the unique id passed by value, the datatype constant,
     group calls and the library's stream can be checked on one GPU with a communicator of one rank that sends to and receives from
