@@ -19,7 +19,7 @@ Reads are packed on the device before the timed region (inputs resident in HBM).
 from its own progress lines; falls back to the repo's CPU port when the binary did not travel),
 `end_to_end` (the drop-in CLI on the same FASTQ files, outputs checked against the reference's md5s) and
 `shard_shapes` (the counting pass on what one of the 8 GPUs of configs[3] and configs[4] holds, and the bench
-workload at k = 45: the two-word variant of the pass beside the direct pass).
+workload at k = 45 and k = 75: the two-word and three-word variants of the pass beside the direct pass).
 """
 import argparse
 import json
@@ -223,19 +223,24 @@ def shard_shapes():
         r1, r2 = synth.make_reads(GENOME, COVERAGE, SEED, genome=genome, pair_lo=lo, pair_hi=min(lo + 250_000, n_pairs))
         g.reads_append_matrix(r1)
         g.reads_append_matrix(r2)
-    res = {}
-    for path, opt in (("super_kmer_pass", 2), ("direct_pass", 1)):
-        g.set_option("count_path", opt)
-        ms = []
-        for it in range(3):
-            h = g.make_kmer_read_distribution(45)
-            if it:
-                ms.append(g.kernel_ms("count"))
-        res[path] = (np.asarray(h).copy(), float(np.mean(ms)), g.kernel_ms("part1") > 0)
-    out["configs[1] reads at k = 45 (two-word keys)"] = {
-        "kmer_instances": int(g.n_instances), "distinct_kmers": int(g.n_distinct), "kernel_ms": res["super_kmer_pass"][1], "direct_pass_kernel_ms": res["direct_pass"][1],
-        "kmers_per_s": g.n_instances / (res["super_kmer_pass"][1] * 1e-3), "super_kmer_pass": bool(res["super_kmer_pass"][2]),
-        "histogram_identical_to_direct_pass": bool(np.array_equal(res["super_kmer_pass"][0], res["direct_pass"][0]))}
+    # ... and at k = 75 (the last k of the reference's default schedule on 150-base reads): three-word keys (kernels_superk3.inc)
+    for kk, name in ((45, "configs[1] reads at k = 45 (two-word keys)"), (75, "configs[1] reads at k = 75 (three-word keys)")):
+        res = {}
+        for path, opt in (("super_kmer_pass", 2), ("direct_pass", 1)):
+            g.set_option("count_path", opt)
+            ms = []
+            for it in range(3):
+                h = g.make_kmer_read_distribution(kk)
+                if it:
+                    ms.append(g.kernel_ms("count"))
+            res[path] = (np.asarray(h).copy(), float(np.mean(ms)), g.kernel_ms("part1") > 0)
+        W = (kk + 31) // 32
+        k_ms = res["super_kmer_pass"][1]
+        out[name] = {
+            "kmer_instances": int(g.n_instances), "distinct_kmers": int(g.n_distinct), "kernel_ms": k_ms, "direct_pass_kernel_ms": res["direct_pass"][1],
+            "kmers_per_s": g.n_instances / (k_ms * 1e-3), "bytes_per_instance": 0.25 + 8 * W + 4,
+            "roofline_frac": g.n_instances * (0.25 + 8 * W + 4) / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "super_kmer_pass": bool(res["super_kmer_pass"][2]),
+            "histogram_identical_to_direct_pass": bool(np.array_equal(res["super_kmer_pass"][0], res["direct_pass"][0]))}
     g.close()
     return out
 

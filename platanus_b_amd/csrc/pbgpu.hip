@@ -272,6 +272,7 @@ static inline unsigned grid_for(u64 n, unsigned block, unsigned max_blocks = 256
 #include "kernels_count.inc"
 #include "kernels_superk.inc"
 #include "kernels_superk2.inc"
+#include "kernels_superk3.inc"
 #include "kernels_sort.inc"
 
 // ------------------------------------------------------------------------------------------------------
@@ -1046,6 +1047,119 @@ static int count_superk2(pb_ctx *ctx, unsigned k, bool *done)
     return PB_OK;
 }
 
+// Super-k-mer pass for three-word keys (65 <= k <= 96; kernels_superk3.inc): the same host side with 32-byte records.  *done = false: the input is not the kind the pass is made for
+// (a few minimizers carry most of it, or nearly every window is a distinct key even with 16 x the buckets): the caller takes the direct pass.
+static int count_superk3(pb_ctx *ctx, unsigned k, bool *done)
+{
+    int rc;
+    *done = false;
+    const u64 lost = (u64)k * ctx->n_reads;
+    const u64 windows = ctx->stream_len > lost + 4096 ? ctx->stream_len - lost : ctx->stream_len;
+    SkwParams<3> p;
+    memset(&p, 0, sizeof(p));
+    p.k = k;
+    p.m = k - (SK2_WIN - 1);
+    // ~2 * SK2_SLOTS windows per final bucket: at sequencing depth that is a third of the table in distinct keys
+    unsigned B = 8;
+    while (((u64)(SK2_SLOTS * 3 / 2) << B) < windows && B < SK_MAX_B) ++B;      // (fewer windows per bucket than the two-word pass: at these k a third of the windows of a 100x set are distinct keys)
+    const bool forced_b = ctx->sk_force_bits >= 2 && ctx->sk_force_bits <= SK_MAX_B;
+    if (forced_b) B = (unsigned)ctx->sk_force_bits;
+    u64 fcap = ctx->sk_fcap && ctx->sk_fcap_for == windows + k ? ctx->sk_fcap : 1ull << 20;
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        p.B = B;
+        p.l1 = std::max(B / 2, B > 9 ? B - 9 : 0u);
+        p.l2 = B - p.l1;
+        p.nx = PB_XCD;
+        const double est_rec = (double)windows * 2.0 / (SK2_WIN + 1.0) + 2.0 * (double)ctx->n_reads;
+        const u64 nb1 = (1ull << p.l1) * PB_XCD, nb2 = 1ull << B;
+        p.cap1 = (u64)(est_rec / (double)nb1 * 1.5) + 4096;
+        p.cap2 = (u32)std::min<double>(est_rec / (double)nb2 * 3.0 + 256.0, 1e9);
+        p.spill_cap = std::max<u64>((u64)(est_rec / 16), 1ull << 16);
+        if ((rc = ensure(ctx, ctx->part_bucket1, nb1 * p.cap1 * 32)) != PB_OK) return rc;
+        if ((rc = ensure(ctx, ctx->part_bucket2, nb2 * (u64)p.cap2 * 32)) != PB_OK) return rc;
+        if ((rc = ensure(ctx, ctx->part_meta, (nb1 * SK_CUR1_STRIDE + 2 * nb2) * 4)) != PB_OK) return rc;
+        if ((rc = ensure(ctx, ctx->part_spill, p.spill_cap * 32)) != PB_OK) return rc;
+        if ((rc = ensure(ctx, ctx->table, fcap * PB_SLOT_WORDS(3) * 8)) != PB_OK) return rc;
+        ctx->table_cap = fcap;
+        p.bucket1 = (u64 *)ctx->part_bucket1.p;
+        p.bucket2 = (u64 *)ctx->part_bucket2.p;
+        p.cursor1 = (u32 *)ctx->part_meta.p;
+        p.cursor2 = p.cursor1 + nb1 * SK_CUR1_STRIDE;
+        p.flag2 = p.cursor2 + nb2;
+        p.spill = (u64 *)ctx->part_spill.p;
+        p.fallback = TableView<3>{(u64 *)ctx->table.p, fcap - 1};
+        p.scalars = (u64 *)ctx->d_scalars.p;
+        const u64 out_cap = std::min<u64>(std::max<u64>(ctx->stream_len, 1), nb2 * (u64)SK2_SLOT_LIMIT);
+        if ((rc = ensure(ctx, ctx->dist_keys, (out_cap + fcap) * 24)) != PB_OK) return rc;
+        if ((rc = ensure(ctx, ctx->dist_counts, (out_cap + fcap) * 4)) != PB_OK) return rc;
+        HIPCHK(hipMemsetAsync(ctx->d_scalars.p, 0, 16 * 8, ctx->stream));
+        HIPCHK(hipMemsetAsync(ctx->part_meta.p, 0, (nb1 * SK_CUR1_STRIDE + 2 * nb2) * 4, ctx->stream));
+        table_init_kernel<3><<<grid_for(fcap * PB_SLOT_WORDS(3), 256, 256 * 32), 256, 0, ctx->stream>>>(p.fallback.slots, fcap);
+        u64 sc[9];
+        {
+            LazyTimer t1(ctx, "part1", 0);
+            const u64 n_tiles = (ctx->stream_len + SK2_OWN - 1) / SK2_OWN;
+            const size_t dig_bytes = (size_t)2 * 4 * (1u << p.l1);
+            const u64 nw64 = (ctx->stream_len + 63) / 64 + PB_STREAM_PAD_WORDS64;
+            sk3_part1_kernel<<<grid_for(n_tiles, 1, 256 * 16), SK1_THREADS, dig_bytes, ctx->stream>>>((const u64 *)ctx->packed.p, cur_mask(ctx), ctx->stream_len, nw64, p);
+            t1.stop();
+            LazyTimer t2(ctx, "part2", 1);
+            const u64 exp_tiles = (u64)(est_rec / (double)nb1) / SK3P_RCAP + 1;
+            const unsigned blocks_per_sub = (unsigned)std::min<u64>(std::max<u64>(exp_tiles / 4, 1), 64);
+            sk3_part2_kernel<<<dim3(blocks_per_sub, (unsigned)nb1), SK_THREADS, 0, ctx->stream>>>(p);
+            t2.stop();
+            LazyTimer t3(ctx, "bucket", 2);
+            sk3_bucket_kernel<<<grid_for(nb2, 1, ctx->opt_bucket_blocks ? (unsigned)ctx->opt_bucket_blocks : 256 * 16), SK2_BUCKET_THREADS, 0, ctx->stream>>>(p, (u64 *)ctx->dist_keys.p, (u32 *)ctx->dist_counts.p, out_cap);
+            t3.stop();
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(sc, ctx->d_scalars.p, 72, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            t1.read(); t2.read(); t3.read();
+        }
+        if (ctx->opt_verbose)
+            fprintf(stderr, "[pbgpu] super-k-mer pass (three-word keys): k %u, m %u, 2^%u buckets (l1 %u), cap1 %llu cap2 %u: windows %llu, records %llu, distinct %llu, abandoned buckets %llu, "
+                            "spilled records %llu, overflow %llu\n", k, p.m, B, p.l1, (unsigned long long)p.cap1, p.cap2, (unsigned long long)sc[0], (unsigned long long)sc[6], (unsigned long long)sc[4],
+                    (unsigned long long)sc[7], (unsigned long long)sc[8], (unsigned long long)sc[1]);
+        if (sc[8] > p.spill_cap) break;                              // a few minimizers carry most of the input: the direct pass takes it
+        // many buckets with more distinct keys than a table holds: not the coverage the bucket count was chosen for -- 4 x the buckets
+        if (!forced_b && sc[7] > nb2 / 64 && B < SK_MAX_B) { B = std::min((unsigned)SK_MAX_B, B + 2); continue; }
+        if (!forced_b && sc[7] > nb2 / 4) break;
+        ctx->stage_ms["seg_compact"] = 0.f;
+        if (sc[7] + sc[8] > 0) {
+            StageTimer t4(ctx, "seg_compact");                       // (stage name as in the k <= 32 pass: flagged buckets through the global table)
+            sk3_flagged_kernel<<<dim3(grid_for(nb2, 1, 1024), 16), 256, 0, ctx->stream>>>(p);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(sc, ctx->d_scalars.p, 72, hipMemcpyDeviceToHost, ctx->stream));
+            if ((rc = t4.stop()) != PB_OK) return rc;
+        }
+        if (sc[1] == 0) {
+            ctx->n_instances = sc[0];
+            ctx->n_distinct = sc[4];
+            ctx->hist_done = 0;
+            ctx->h_hist_valid = false;
+            ctx->sk_records = sc[6];
+            ctx->sk_bits = B;
+            ctx->sk_flagged = sc[7];
+            ctx->sk_spilled = sc[8];
+            ctx->stage_ms["sk_bucket_bits"] = (float)B;
+            ctx->stage_ms["sk_flagged_buckets"] = (float)sc[7];
+            ctx->stage_ms["sk_spilled_records"] = (float)sc[8];
+            ctx->stage_ms["sk_records_per_1k_windows"] = sc[0] ? (float)(1000.0 * (double)sc[6] / (double)sc[0]) : 0.f;
+            ctx->stage_ms["compact"] = 0.f;
+            ctx->stage_ms["count"] = ctx->stage_ms["part1"] + ctx->stage_ms["part2"] + ctx->stage_ms["bucket"] + ctx->stage_ms["seg_compact"];
+            if (sc[7] + sc[8] > 0 && (rc = table_to_arrays<3>(ctx, ctx->table_cap, true)) != PB_OK) return rc;      // what went through the global table
+            *done = true;
+            return PB_OK;
+        }
+        fcap <<= 4;                                                   // the fallback table overflowed: once more with a larger one (remembered for this stream)
+        ctx->sk_fcap = fcap;
+        ctx->sk_fcap_for = windows + k;
+        if (fcap > (1ull << 34)) break;
+    }
+    ctx->stage_ms["part1"] = ctx->stage_ms["part2"] = ctx->stage_ms["bucket"] = ctx->stage_ms["seg_compact"] = 0.f;
+    return PB_OK;
+}
+
 // scratch[2] (keys, n * W words) and scratch[3] (u32 counts) -> ctx->ret_keys / ret_counts, ascending by the 2k-bit key value
 // (counter.h:916-951 std::sort); the sorted set becomes the context's retained set
 static int sort_retained(pb_ctx *ctx, u64 n)
@@ -1307,11 +1421,11 @@ int pb_count(pb_ctx *ctx, unsigned k, uint64_t *occ_hist, uint64_t *max_occ, uin
     if ((rc = ensure(ctx, ctx->d_scalars, 16 * 8)) != PB_OK) return rc;
     bool done = false;
     // small inputs take the direct pass unless pb_set_option("count_path") says otherwise
-    const bool want_sk = k <= 64 && ctx->stream_len >= k &&
+    const bool want_sk = k <= 96 && ctx->stream_len >= k &&
                          (ctx->opt_count_path ? ctx->opt_count_path == 2 : ctx->stream_len >= (1ull << 22));
     ctx->sk_records = 0;
     if (want_sk) {
-        if ((rc = ctx->W == 1 ? count_superk(ctx, k, &done) : count_superk2(ctx, k, &done)) != PB_OK) return rc;
+        if ((rc = ctx->W == 1 ? count_superk(ctx, k, &done) : ctx->W == 2 ? count_superk2(ctx, k, &done) : count_superk3(ctx, k, &done)) != PB_OK) return rc;
     }
     if (!done) {
         switch (ctx->W) {

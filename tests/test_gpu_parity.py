@@ -523,6 +523,44 @@ def test_superkmer_two_word_keys(k, gpu, oracle_built, monkeypatch):
     _superk_case(gpu, oracle_built, np.concatenate([r1, r2]), k)
 
 
+@pytest.mark.parametrize("k", [65, 66, 72, 75, 77, 82, 83, 84, 95, 96])
+def test_superkmer_three_word_keys(k, gpu, oracle_built, monkeypatch):
+    """r3: 65 <= k <= 96 through the super-k-mer pass for three-word keys (kernels_superk3.inc: minimizers of k - 19 = 46 .. 77 bases hashed on
+    both strands, 32-byte records, table of three-word keys claimed on the low word) against the oracle: histogram, max_occ, the retained
+    (key,count) sets.  k = 65 / 96 are the ends of the range (2 and 64 bits in the top word), 82 / 83 / 84 sit around the 64-base
+    minimizer, 75 is the last k of the reference's default schedule on 150-base reads; reads carry N bases."""
+    from platanus_b_amd import synth
+    monkeypatch.setitem(GpuCounter.default_options, "count_path", COUNT_PATH["superk"])
+    r1, r2 = synth.make_reads(60_000, 40, seed=600 + k, n_rate=0.002)
+    _superk_case(gpu, oracle_built, np.concatenate([r1, r2]), k)
+
+
+@pytest.mark.parametrize("bits,k", [(3, 75), (9, 65), (12, 96), (12, 83)])
+def test_superkmer_three_word_keys_small_tables_and_low_complexity(bits, k, gpu, oracle_built, monkeypatch):
+    """Three-word keys with 8 .. 4096 buckets: the record table is far too small (windows go straight into the table of keys), tables of
+    keys overflow (flagged buckets through the global table), poly-A / poly-T reads bring keys whose low word is all ones (the empty mark:
+    their buckets are flagged) and long runs in one bucket (spill list)."""
+    from platanus_b_amd import synth
+    monkeypatch.setitem(GpuCounter.default_options, "count_path", COUNT_PATH["superk"])
+    monkeypatch.setitem(GpuCounter.default_options, "sk_bucket_bits", bits)
+    r1, r2 = synth.make_reads(70_000, 50, seed=700 + bits + k, err=0.01, n_rate=0.001)
+    poly = np.full((40, r1.shape[1]), 3, dtype=np.uint8)
+    poly[:20] = 0
+    poly[::3, 70] = 1
+    _superk_case(gpu, oracle_built, np.concatenate([r1, poly, r2]), k, cutoffs=(1, 3), must_take_path=False)
+
+
+def test_superkmer_three_word_keys_low_coverage_and_short_reads(gpu, oracle_built, monkeypatch):
+    """2x coverage with 2 % errors at k = 75 (nearly every window a distinct key: the pass repeats itself with more buckets or hands over to
+    the direct pass -- same results), and reads shorter than k (nothing to count)."""
+    from platanus_b_amd import synth
+    monkeypatch.setitem(GpuCounter.default_options, "count_path", COUNT_PATH["superk"])
+    r1, r2 = synth.make_reads(300_000, 2, seed=791, err=0.02)
+    _superk_case(gpu, oracle_built, np.concatenate([r1, r2]), 75, cutoffs=(1,), must_take_path=False)
+    short = synth.make_reads(20_000, 10, seed=778, read_len=70)[0]
+    _superk_case(gpu, oracle_built, short, 75, cutoffs=(1,), must_take_path=False)
+
+
 @pytest.mark.parametrize("form", [1, 2])
 @pytest.mark.parametrize("bits,k", [(3, 45), (9, 33), (12, 64), (12, 48)])
 def test_superkmer_two_word_keys_both_forms_of_the_bucket_kernel(form, bits, k, gpu, oracle_built, monkeypatch):

@@ -5,7 +5,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from platanus_b_amd import synth
+from platanus_b_amd import binding
 from platanus_b_amd.binding import GpuCounter
+if os.environ.get("PB_LIB"):
+    binding.LIB_PATH = os.path.abspath(os.environ["PB_LIB"])       # (a development build of the library)
 g = GpuCounter(0)
 gen = synth.make_genome(5_000_000, 1)
 n_pairs = 5_000_000 * 100 // 300
