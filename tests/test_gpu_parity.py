@@ -796,13 +796,13 @@ def test_superkmer_ragged_reads(gpu, oracle_built, monkeypatch):
 
 def test_superkmer_random_differential():
     """tools/fuzz_count.py: random genomes (with low-complexity inserts), coverages, error / N rates, mixed read lengths, k in
-    1..32 and forced bucket counts -- the super-k-mer pass and the direct pass must agree on histogram, keys and counts."""
+    1..96 (one-, two- and three-word keys) and forced bucket counts -- the super-k-mer passes and the direct pass must agree on histogram, keys and counts."""
     import subprocess
     import sys
     from conftest import ROOT
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_count.py"), "24", "11"], capture_output=True, text=True, timeout=600)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_count.py"), "30", "11"], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
-    assert "24 cases, 0 mismatches" in p.stdout
+    assert "30 cases, 0 mismatches" in p.stdout
 
 
 @pytest.mark.parametrize("form", [1, 2])

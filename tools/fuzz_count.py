@@ -1,5 +1,5 @@
 """Development aid: differential test of the super-k-mer counting pass against the direct (global table) pass on random
-inputs -- random genome size, coverage, error and N rates, read lengths (mixed), k in 1..64 (two-word keys above 32: kernels_superk2.inc), bucket bits.  Both run on the
+inputs -- random genome size, coverage, error and N rates, read lengths (mixed), k in 1..96 (two-word keys above 32: kernels_superk2.inc, three-word keys above 64: kernels_superk3.inc), bucket bits.  Both run on the
 GPU, so hundreds of cases take a minute.  usage: python tools/fuzz_count.py [n_cases] [seed]"""
 import os
 import sys
@@ -25,7 +25,8 @@ def main():
         cov = float(rng.choice([2, 10, 40, 120]))
         err = float(rng.choice([0.0, 0.005, 0.03]))
         n_rate = float(rng.choice([0.0, 0.001, 0.02]))
-        k = int(rng.integers(1, 33)) if rng.random() < 0.6 else int(rng.integers(33, 65))
+        u = rng.random()
+        k = int(rng.integers(1, 33)) if u < 0.45 else int(rng.integers(33, 65)) if u < 0.75 else int(rng.integers(65, 97))
         n_bases, reads = 0, []
         while n_bases < G * cov and n_bases < 6_000_000:
             L = int(rng.choice([int(rng.integers(1, 60)), 100, 150, 151, 250, int(rng.integers(300, 3000))]))
