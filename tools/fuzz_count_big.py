@@ -37,7 +37,7 @@ def main():
         cov = float(rng.choice([3, 15, 60, 120]))
         err = float(rng.choice([0.0, 0.005, 0.02]))
         n_rate = float(rng.choice([0.0, 0.0005]))
-        k = int(rng.choice([32, 32, 31, 25, 21, 17, 33, 41, 48, 55, 64]))
+        k = int(rng.choice([32, 32, 31, 25, 21, 17, 33, 41, 48, 55, 64, 65, 75, 83, 96]))
         L = int(rng.choice([100, 150, 250]))
         n_reads = min(int(G * cov / L), 400_000_000 // L)
         g = GpuCounter(0)
