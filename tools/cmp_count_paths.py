@@ -1,5 +1,5 @@
 """development: the two forms of the two-word bucket kernel against each other (33 <= k <= 64), or the three-word super-k-mer pass
-against the direct pass (65 <= k <= 96), on a set large enough for many buckets per block.  usage: python tools/dbg_sk2_forms.py [genome bp] [k]"""
+against the direct pass (65 <= k <= 96), on a set large enough for many buckets per block.  usage: python tools/cmp_count_paths.py [genome bp] [k]"""
 import sys, os
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
