@@ -353,39 +353,71 @@ struct Driver {
     // thread while this one lists the edge k-mers and the device filters the reads.
     template <int W> void save_graph_and_contig_table(unsigned graph_k, unsigned next_k, double ratio)
     {
-        std::vector<uint8_t> bases;
-        std::vector<u64> off{0};
-        std::vector<u16> vals;
-        double strings_s = 0;
-        std::exception_ptr err;
-        struct Joiner { std::thread t; ~Joiner() { if (t.joinable()) t.join(); } } strings;
-        strings.t = std::thread([&]() {
-            const auto t0 = std::chrono::steady_clock::now();
-            try {
-                graph<W>().for_each_contig_string(next_k, ratio, [&](const std::vector<unsigned char> &str, u16 occ) {
-                    bases.insert(bases.end(), str.begin(), str.end());
-                    off.push_back(bases.size());
-                    vals.push_back(occ);
-                });
-            } catch (...) { err = std::current_exception(); }
-            strings_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        });
+        // leftStraightTable's sequence cut into runs: four threads collect the strings, this one and a fifth list the edge k-mers; every
+        // result is put together in the table's order (large graphs only: a 5 Mbp genome has 10^4 nodes and no use for threads)
+        Graph<W> &g = graph<W>();
+        const unsigned n_str = g.left.size() >= (1u << 16) ? 4u : 1u, n_edge = g.left.size() >= (1u << 16) ? 2u : 1u;
+        const auto cuts_s = g.left_cuts(n_str), cuts_e = n_edge == n_str ? cuts_s : g.left_cuts(n_edge);
+        struct Strings { std::vector<uint8_t> bases; std::vector<u64> off; std::vector<u16> vals; std::exception_ptr err; double s = 0; };
+        std::vector<Strings> part(n_str);
+        struct Joiner { std::vector<std::thread> t; ~Joiner() { for (auto &x : t) if (x.joinable()) x.join(); } } workers;
+        for (unsigned i = 0; i < n_str; ++i)
+            workers.t.emplace_back([&, i]() {
+                const auto t0 = std::chrono::steady_clock::now();
+                Strings &o = part[i];
+                try {
+                    g.for_each_contig_string_range(cuts_s[i], cuts_s[i + 1], next_k, ratio, [&](const std::vector<unsigned char> &str, u16 occ) {
+                        o.bases.insert(o.bases.end(), str.begin(), str.end());
+                        o.off.push_back(o.bases.size());
+                        o.vals.push_back(occ);
+                    });
+                } catch (...) { o.err = std::current_exception(); }
+                o.s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            });
         {
-            std::vector<u64> edge;
+            std::vector<std::vector<u64>> edge(n_edge);
+            std::vector<std::exception_ptr> eerr(n_edge);
             Tick t0("edge k-mers (host)");
-            graph<W>().save_edge_kmers([&](const Key<W> &key, u16) { for (int w = 0; w < W; ++w) edge.push_back(key.w[w]); }, next_k);
+            {
+                Joiner helpers;
+                for (unsigned i = 1; i < n_edge; ++i)
+                    helpers.t.emplace_back([&, i]() {
+                        try { g.save_edge_kmers_range(cuts_e[i], cuts_e[i + 1], [&](const Key<W> &key, u16) { for (int w = 0; w < W; ++w) edge[i].push_back(key.w[w]); }, next_k); }
+                        catch (...) { eerr[i] = std::current_exception(); }
+                    });
+                g.save_edge_kmers_range(cuts_e[0], cuts_e[1], [&](const Key<W> &key, u16) { for (int w = 0; w < W; ++w) edge[0].push_back(key.w[w]); }, next_k);
+            }
+            for (auto &e : eerr) if (e) std::rethrow_exception(e);
+            for (unsigned i = 1; i < n_edge; ++i) edge[0].insert(edge[0].end(), edge[i].begin(), edge[i].end());
             log("extracting reads (containing kmer used in contig assemble)...");
             u64 kept = 0;
             t0.stop();
             Tick t("read filter (device)");
-            chk(pb_reads_filter(ctx, graph_k, edge.data(), edge.size() / W, &kept));
+            chk(pb_reads_filter(ctx, graph_k, edge[0].data(), edge[0].size() / W, &kept));
         }
         {
             Tick t("wait for the contig strings (host)");
-            strings.t.join();
+            for (auto &x : workers.t) x.join();
         }
-        g_clock.add("contig strings (host thread, beside edge k-mers + read filter)", strings_s);
-        if (err) std::rethrow_exception(err);
+        double strings_s = 0;
+        for (auto &o : part) { if (o.err) std::rethrow_exception(o.err); strings_s = std::max(strings_s, o.s); }
+        g_clock.add("contig strings (host threads, beside edge k-mers + read filter)", strings_s);
+        std::vector<uint8_t> bases;
+        std::vector<u64> off{0};
+        std::vector<u16> vals;
+        {
+            Tick t("contig strings put together (host)");
+            size_t nb = 0, nv = 0;
+            for (auto &o : part) { nb += o.bases.size(); nv += o.vals.size(); }
+            bases.reserve(nb); off.reserve(nv + 1); vals.reserve(nv);
+            for (auto &o : part) {
+                const u64 base = bases.size();
+                bases.insert(bases.end(), o.bases.begin(), o.bases.end());
+                for (u64 v : o.off) off.push_back(base + v);
+                vals.insert(vals.end(), o.vals.begin(), o.vals.end());
+                std::vector<uint8_t>().swap(o.bases);
+            }
+        }
         u64 nw = 0;
         Tick t("contig table (device)");
         chk(pb_contig_table_build(ctx, next_k, bases.data(), off.data(), vals.data(), vals.size(), &nw));

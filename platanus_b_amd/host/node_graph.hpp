@@ -887,12 +887,28 @@ struct Graph {
 
     // graph.h:1877-1939
     // put(canonical key, coverage): overwrite semantics (counter.h:90 setOccurrenceValue)
+    typedef typename std::unordered_map<K, Straight, KeyHash<W>>::iterator LeftIt;
+    // `parts` + 1 iterators that cut leftStraightTable's sequence into runs of equal length (one walk): the read-only passes over the
+    // table -- edge k-mers, contig strings -- then run on several threads, each on its run, and their results are put together in order
+    std::vector<LeftIt> left_cuts(unsigned parts)
+    {
+        std::vector<LeftIt> cuts;
+        const size_t n = left.size();
+        size_t i = 0, next = 0;
+        unsigned c = 0;
+        for (auto it = left.begin(), end = left.end(); it != end; ++it, ++i)
+            if (i == next && c < parts) { cuts.push_back(it); ++c; next = n * c / parts; if (next <= i) next = i + 1; }
+        while (cuts.size() < parts + 1) cuts.push_back(left.end());
+        return cuts;
+    }
     template <typename PUT>
-    void save_edge_kmers(PUT &&put, unsigned next_k) const
+    void save_edge_kmers(PUT &&put, unsigned next_k) { save_edge_kmers_range(left.begin(), left.end(), put, next_k); }
+    template <typename PUT>
+    void save_edge_kmers_range(LeftIt from, LeftIt to, PUT &&put, unsigned next_k) const
     {
         const unsigned diff = next_k - k;
-        for (auto &e : left) {
-            const Straight &st = e.second;
+        for (auto eit = from; eit != to; ++eit) {
+            const Straight &st = eit->second;
             if (st.coverage == 65535) continue;
             auto emit_run = [&](u64 first_pos, u64 count) {
                 // k-mers whose 3' bases are at positions first_pos, first_pos-1, ... (count of them): the first one is taken out of the
@@ -927,11 +943,13 @@ struct Graph {
     // junction] + [left junction base] + straight + [right junction base] + [<= diff head bases ...] (left -> right, codes
     // 0..3) and occ = (u16)(coverage * ratio + 0.5).  f(str, occ) is called for strings of at least next_k bases.
     template <typename F>
-    void for_each_contig_string(unsigned next_k, double ratio, F &&f)
+    void for_each_contig_string(unsigned next_k, double ratio, F &&f) { for_each_contig_string_range(left.begin(), left.end(), next_k, ratio, f); }
+    template <typename F>
+    void for_each_contig_string_range(LeftIt from, LeftIt to, unsigned next_k, double ratio, F &&f)
     {
         const u64 diff = next_k - k;
         std::vector<unsigned char> str;            // left -> right
-        for (auto it = left.begin(), end = left.end(); it != end; ++it) {
+        for (auto it = from, end = to; it != end; ++it) {
             const Straight *st = &it->second;
             if (st->coverage == 65535) continue;
             str.clear();
