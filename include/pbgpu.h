@@ -52,13 +52,19 @@ void        pb_destroy(pb_ctx *ctx);
 const char *pb_last_error(const pb_ctx *ctx);          /* ctx may be NULL: error of the last failed pb_create */
 /* Choice between equivalent implementations of a call (tests, A/B timing).  No option changes a result; the library reads no
  * environment variable for this.  Not in the reference (its only knobs are -t and -m).
- *   "count_path"      0 = by input size (default), 1 = direct pass (one lane per window, global table), 2 = super-k-mer pass (k <= 64:
- *                     one-word keys kernels_superk.inc, two-word keys kernels_superk2.inc; larger k takes the direct pass anyway)
+ *   "count_path"      0 = by input size (default), 1 = direct pass (one lane per window, global table), 2 = super-k-mer pass (k <= 96:
+ *                     one-word keys kernels_superk.inc, two-word keys kernels_superk2.inc, three-word keys kernels_superk3.inc; larger k
+ *                     takes the direct pass anyway)
  *   "sk_bucket_bits"  0 = by input size, 2..20 = bucket bits of the super-k-mer pass;  "sk_l1_bits" 0 = by the bucket bits, 1..9
  *   "dist_design"     pb_dist_count: 0 = run records exchanged before the counting where that applies, 1 = always count + merge
  *   "merge_table" / "merge_16b"  1 = owner-side merge through the global table / with 16-byte records
  *   "chain_rank_full" 1 = pointer jumping over all chain states;  "grid_cap" n = cap on the grid of the direct counting kernel
- *   "verbose"         1 = one line per super-k-mer pass attempt on stderr (bucket bits, records, flagged buckets, spilled records) */
+ *   "verbose"         1 = one line per super-k-mer pass attempt on stderr (bucket bits, records, flagged buckets, spilled records)
+ *   "sk_bucket_form"  2 (default) / 1 = which form of the bucket kernel counts a final bucket (k <= 32 and two-word keys have both)
+ *   "sk_bucket_blocks" n = grid of the bucket kernel;  "graph" 1 (default) = the k <= 32 pass replayed as a captured HIP graph
+ *   "hist_zeroed"     1 = the caller's histogram array is zero on entry (only the non-zero head is written)
+ *   "sk_out_div"      n = (key, count) arrays of the k <= 32 pass sized for windows / n keys (large inputs: 5 by themselves; a pass
+ *                     that finds more is repeated once with the number it counted) */
 int         pb_check_option(const char *name, long value);   /* PB_OK if pb_set_option would take it (no context, no GPU: launchers check before they fork) */
 int         pb_set_option(pb_ctx *ctx, const char *name, long value);
 /* name, CU count, HBM bytes of the context's device (for reports; not in the reference) */
