@@ -255,6 +255,22 @@ int pb_nodes_clean_decide(pb_ctx *ctx, unsigned k, uint64_t n_straight, const ui
  * against bases[offsets[2p+1] .. offsets[2p+2]); dist[p] = unit-cost edit distance. */
 int pb_edit_distances(pb_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, uint64_t n_pairs, uint64_t *dist);
 
+/* ---- the local de Bruijn graphs of gap closing, a batch of gaps per call ------------------------------------------
+ * Replaces, for every gap of the batch at once, Counter<KMER>::countKmerForGapClose (counter.h:1015-1056: the FORWARD k-mer of every window
+ * without an unknown base, counts saturating at 65534; called per gap at gapCloseDBG.h:91-120) and
+ * BruijnGraph<KMER>::makeBruijnGraphForGapClose (graph.h:2116-2345: strand-specific junction / straight nodes over the k-mers with
+ * value >= min_coverage, start k-mers in ascending key order: counter.h:168-175; called at gapCloseDBG.h:132-161).
+ * Gap g owns the sequences seq_first[g] .. seq_first[g+1]-1; sequence s = codes[seq_off[s] .. seq_off[s+1]) (0..3, 4 = unknown).  The caller
+ * passes the sequences that are counted: the reference skips a gap's first GAP_CANDIDATE_SEQ_1ST = 2 entries (counter.h:1023).
+ * pb_gap_graphs_fetch: the nodes gap by gap, IN THE ORDER of the reference's setJunctionTable / insertStraight calls (inserted in that order
+ * into tables with the reference's hashers they iterate as the reference's do: tests/golden/gapclose_*.txt are dumps of the reference's own
+ * tables).  node_first[n_gaps+1]; per node kind (1 straight, 0 junction), coverage, out ((left flags << 4) | right flags), length in k-mers;
+ * word_off[n_nodes+1] into words: a straight's sequence ((length + k + 31) / 32 words, base p from the 3' end at bits 2p: graph.h:67-71,
+ * 2320-2338), a junction's k-mer (ceil(k / 32) words, least significant first). */
+int pb_gap_graphs_build(pb_ctx *ctx, unsigned k, long min_coverage, uint64_t n_gaps, const uint64_t *seq_first, uint64_t n_seqs, const uint64_t *seq_off,
+                        const uint8_t *codes, uint64_t *n_nodes, uint64_t *n_words);
+int pb_gap_graphs_fetch(pb_ctx *ctx, uint64_t *node_first, uint8_t *kind, uint16_t *coverage, uint8_t *out, uint32_t *length, uint64_t *word_off, uint64_t *words);
+
 /* ---- multi-k rounds (assemble.cpp:392-498) ------------------------------------------------------------------- */
 /* saveEdgeKmer + pickupReadMatchedEdgeKmer (graph.h:1877-1939, counter.h:869-910): keep a read iff one of its N-free
  * k-mers (k = the finished graph's k) is among edge_keys[n_edge*W] (canonical).  Cumulative like the reference's readFP:

@@ -152,3 +152,66 @@ def parse_file_check(path: str, max_threads: int = 8, parts: int = 1):
     nr, npc = C.c_uint64(), C.c_uint64()
     rc = l.pbo_parse_file_check_parts(path.encode(), max_threads, parts, C.byref(nr), C.byref(npc))
     return rc, nr.value, npc.value
+
+
+def gap_graphs(k: int, min_cov: int, seq_first: np.ndarray, seq_off: np.ndarray, codes: np.ndarray):
+    """gapclose.hpp: the local de Bruijn graphs of a batch of gaps (counter.h:1015-1056 + graph.h:2116-2345).  Gap g owns the sequences
+    seq_first[g] .. seq_first[g + 1] - 1, sequence s = codes[seq_off[s] : seq_off[s + 1]] (0..3, 4 = N).  Returns a dict of arrays
+    (nodes in the reference's insertion order: node_first, kind 1 = straight / 0 = junction, cov, out, length, word_off, words) and the
+    per-gap table dumps (iteration order of a fresh Graph<W> after those insertions)."""
+    L = lib()
+    L.pbo_gap_graphs_run.argtypes = [C.c_uint, C.c_long, C.c_ulonglong, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
+    L.pbo_gap_graphs_fetch.argtypes = [C.c_void_p] * 7
+    L.pbo_gap_graphs_dump.argtypes = [C.c_ulonglong]
+    L.pbo_gap_graphs_dump.restype = C.c_char_p
+    seq_first = np.ascontiguousarray(seq_first, dtype=np.uint64)
+    seq_off = np.ascontiguousarray(seq_off, dtype=np.uint64)
+    codes = np.ascontiguousarray(codes, dtype=np.uint8)
+    n_gaps = len(seq_first) - 1
+    nn, nw = C.c_ulonglong(), C.c_ulonglong()
+    rc = L.pbo_gap_graphs_run(k, min_cov, n_gaps, seq_first.ctypes.data, seq_off.ctypes.data, codes.ctypes.data, C.byref(nn), C.byref(nw))
+    if rc != 0:
+        raise RuntimeError(f"pbo_gap_graphs_run: {rc}")
+    out = {"node_first": np.zeros(n_gaps + 1, dtype=np.uint64), "kind": np.zeros(nn.value, dtype=np.uint8), "cov": np.zeros(nn.value, dtype=np.uint16),
+           "out": np.zeros(nn.value, dtype=np.uint8), "length": np.zeros(nn.value, dtype=np.uint32), "word_off": np.zeros(nn.value + 1, dtype=np.uint64),
+           "words": np.zeros(nw.value, dtype=np.uint64)}
+    L.pbo_gap_graphs_fetch(*(out[n].ctypes.data for n in ("node_first", "kind", "cov", "out", "length", "word_off", "words")))
+    dumps = [L.pbo_gap_graphs_dump(g).decode() for g in range(n_gaps)]
+    return out, dumps
+
+
+def gap_graphs_reference(k: int, min_cov: int, seq_first: np.ndarray, seq_off: np.ndarray, codes: np.ndarray):
+    """The same tables from the REFERENCE's own functions (oracle/_ref/gapclose_ref, built from ref_harness/gapclose_ref.cpp where
+    /root/reference exists): per-gap dumps in the format of gap_graphs()'s second result."""
+    import struct
+    import subprocess
+    import tempfile
+    exe = os.path.join(_HERE, "_ref", "gapclose_ref")
+    seq_first = np.ascontiguousarray(seq_first, dtype=np.uint64)
+    seq_off = np.ascontiguousarray(seq_off, dtype=np.uint64)
+    codes = np.ascontiguousarray(codes, dtype=np.uint8)
+    with tempfile.NamedTemporaryFile(suffix=".bin") as f:
+        f.write(struct.pack("<IqQ", k, min_cov, len(seq_first) - 1))
+        f.write(seq_first.tobytes())
+        f.write(struct.pack("<Q", len(seq_off) - 1))
+        f.write(seq_off.tobytes())
+        f.write(codes[:int(seq_off[-1])].tobytes())
+        f.flush()
+        p = subprocess.run([exe, f.name], capture_output=True, text=True, timeout=600)
+    if p.returncode != 0:
+        raise RuntimeError(f"gapclose_ref: {p.returncode} {p.stderr[-500:]}")
+    return split_gap_dump(p.stdout)
+
+
+def split_gap_dump(text: str):
+    dumps, cur = [], None
+    for ln in text.splitlines(keepends=True):
+        if ln.startswith("G "):
+            if cur is not None:
+                dumps.append(cur)
+            cur = ""
+        elif cur is not None:
+            cur += ln
+    if cur is not None:
+        dumps.append(cur)
+    return dumps

@@ -1,0 +1,76 @@
+// TEST INFRASTRUCTURE ONLY.  Calls the REFERENCE's own Counter<KMER>::countKmerForGapClose (counter.h:1015-1056) and
+// BruijnGraph<KMER>::makeBruijnGraphForGapClose (graph.h:2116-2345) on a batch of gaps and prints the tables they leave, in the tables'
+// own iteration order.  This file is ours; the reference's headers and objects are taken where they lie (oracle/Makefile, target
+// `ref`: $(REF)/*.h by -I, the objects of $(OUT)/obj without main.o) and nothing of them is copied.  Output goes to oracle/_ref/.
+// usage: gapclose_ref INPUT.bin > dump.txt
+//   INPUT.bin: u32 k, i64 min_coverage, u64 n_gaps, u64 seq_first[n_gaps + 1], u64 n_seqs, u64 seq_off[n_seqs + 1], u8 codes[] (0..3, 4 = N)
+//   dump: per gap "G <index>", then "J <key words, most significant first> <coverage> <out>" per junction and
+//         "S <length> <coverage> <out> <sequence words>" per straight node (hex), as oracle/src/capi.cpp pbo_gap_graphs_dump prints them
+// (compiled with -fno-access-control: the tables are private members of BruijnGraph)
+#include "counter.h"
+#include "graph.h"
+#include "gapClose.h"
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+
+static void key_words(const Kmer31Key &k, unsigned W, std::vector<unsigned long long> &w) { (void)W; w.assign(1, k); }
+template <typename B> static void key_words(const B &k, unsigned W, std::vector<unsigned long long> &w) { w.assign(k.value, k.value + W); }
+
+template <typename KMER>
+static void run(unsigned k, long min_cov, const std::vector<unsigned long long> &seq_first, const std::vector<unsigned long long> &seq_off, const std::vector<unsigned char> &codes)
+{
+    const unsigned W = (k + 31) / 32;
+    for (size_t g = 0; g + 1 < seq_first.size(); ++g) {
+        std::vector<std::vector<char> > seq(GapClose::GAP_CANDIDATE_SEQ_1ST);        // the entries the reference skips
+        for (unsigned long long s = seq_first[g]; s < seq_first[g + 1]; ++s) seq.push_back(std::vector<char>(codes.begin() + seq_off[s], codes.begin() + seq_off[s + 1]));
+        Counter<KMER> counter;
+        counter.setKmerLength(k);
+        counter.countKmerForGapClose(seq);
+        BruijnGraph<KMER> graph;
+        graph.setKmerLength(k);
+        graph.makeBruijnGraphForGapClose(counter, min_cov);
+        printf("G %zu\n", g);
+        std::vector<unsigned long long> w;
+        for (auto it = graph.junctionTable.begin(); it != graph.junctionTable.end(); ++it) {
+            key_words(it->first, W, w);
+            printf("J");
+            for (int i = (int)W - 1; i >= 0; --i) printf(" %llx", w[i]);
+            printf(" %x %x\n", (unsigned)it->second.coverage, (unsigned)it->second.out);
+        }
+        for (auto it = graph.leftStraightTable.begin(); it != graph.leftStraightTable.end(); ++it) {
+            const Straight &st = it->second;
+            printf("S %llx %x %x", (unsigned long long)st.length, (unsigned)st.coverage, (unsigned)st.out);
+            const unsigned long long nb = st.length + k - 1;
+            for (unsigned long long i = 0; i < (nb + 31) / 32; ++i) {
+                unsigned long long v = i < st.seq.size() ? st.seq[i] : 0;
+                if (i == (nb + 31) / 32 - 1 && (nb % 32)) v &= ~0ull >> (64 - 2 * (nb % 32));
+                printf(" %llx", v);
+            }
+            printf("\n");
+        }
+    }
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 2) return 2;
+    FILE *f = fopen(argv[1], "rb");
+    if (!f) return 2;
+    uint32_t k = 0; int64_t mc = 0; uint64_t ng = 0, ns = 0;
+    if (fread(&k, 4, 1, f) != 1 || fread(&mc, 8, 1, f) != 1 || fread(&ng, 8, 1, f) != 1) return 3;
+    std::vector<unsigned long long> seq_first(ng + 1);
+    if (fread(seq_first.data(), 8, ng + 1, f) != ng + 1 || fread(&ns, 8, 1, f) != 1) return 3;
+    std::vector<unsigned long long> seq_off(ns + 1);
+    if (fread(seq_off.data(), 8, ns + 1, f) != ns + 1) return 3;
+    std::vector<unsigned char> codes(seq_off[ns]);
+    if (!codes.empty() && fread(codes.data(), 1, codes.size(), f) != codes.size()) return 3;
+    fclose(f);
+    if (k <= 32) run<Kmer31>(k, mc, seq_first, seq_off, codes);
+    else if (k <= 64) run<KmerN<Binstr63> >(k, mc, seq_first, seq_off, codes);
+    else if (k <= 96) run<KmerN<Binstr95> >(k, mc, seq_first, seq_off, codes);
+    else if (k <= 128) run<KmerN<Binstr127> >(k, mc, seq_first, seq_off, codes);
+    else if (k <= 160) run<KmerN<Binstr159> >(k, mc, seq_first, seq_off, codes);
+    else return 4;
+    return 0;
+}

@@ -404,3 +404,91 @@ extern "C" int pbo_parse_file_check(const char *path, unsigned max_threads, unsi
 {
     return pbo_parse_file_check_parts(path, max_threads, 1, n_reads, n_pieces);
 }
+
+// ---- local de Bruijn graphs of gap closing (gapclose.hpp): a batch of gaps, nodes in the reference's insertion order ---------------------
+#include "gapclose.hpp"
+#include <sstream>
+namespace {
+struct GapResult {
+    std::vector<unsigned long long> node_first, word_off, words;
+    std::vector<unsigned char> kind, out;
+    std::vector<unsigned short> cov;
+    std::vector<unsigned> length;
+    std::vector<std::string> dumps;          // per gap: the tables of a fresh Graph<W> after the insertions, in iteration order
+};
+GapResult g_gap;
+
+template <int W>
+void gap_run(unsigned k, long min_cov, unsigned long long n_gaps, const unsigned long long *seq_first, const unsigned long long *seq_off, const unsigned char *codes)
+{
+    g_gap = GapResult();
+    g_gap.node_first.push_back(0);
+    g_gap.word_off.push_back(0);
+    for (unsigned long long g = 0; g < n_gaps; ++g) {
+        pbo::GapGraph<W> gg;
+        gg.k = k;
+        std::vector<std::vector<unsigned char>> seqs;
+        for (unsigned long long s = seq_first[g]; s < seq_first[g + 1]; ++s) seqs.emplace_back(codes + seq_off[s], codes + seq_off[s + 1]);
+        gg.count(seqs);
+        const auto nodes = gg.make_graph(min_cov);
+        pbh::Graph<W> gr;
+        gr.set_k(k);
+        for (const auto &n : nodes) {
+            g_gap.kind.push_back(n.straight ? 1 : 0);
+            g_gap.cov.push_back(n.straight ? n.st.coverage : n.jn.coverage);
+            g_gap.out.push_back(n.straight ? n.st.out : n.jn.out);
+            g_gap.length.push_back(n.straight ? (unsigned)n.st.length : 1u);
+            if (n.straight) { for (auto w : n.st.seq) g_gap.words.push_back(w); gr.insert_straight(n.st); }
+            else { for (int w = 0; w < W; ++w) g_gap.words.push_back(n.key.w[w]); gr.junctions[n.key] = n.jn; }
+            g_gap.word_off.push_back(g_gap.words.size());
+        }
+        g_gap.node_first.push_back(g_gap.kind.size());
+        // the tables as the reference's own would be walked (format shared with oracle/ref_harness/gapclose_ref.cpp)
+        std::ostringstream o;
+        o << std::hex;
+        for (auto &e : gr.junctions) { o << "J"; for (int w = W - 1; w >= 0; --w) o << " " << e.first.w[w]; o << " " << e.second.coverage << " " << (unsigned)e.second.out << "\n"; }
+        for (auto &e : gr.left) {
+            o << "S " << e.second.length << " " << e.second.coverage << " " << (unsigned)e.second.out;
+            const unsigned long long nb = e.second.length + k - 1;
+            for (unsigned long long i = 0; i < (nb + 31) / 32; ++i) {
+                unsigned long long w = i < e.second.seq.size() ? e.second.seq[i] : 0;
+                if (i == (nb + 31) / 32 - 1 && (nb % 32)) w &= ~0ull >> (64 - 2 * (nb % 32));
+                o << " " << w;
+            }
+            o << "\n";
+        }
+        g_gap.dumps.push_back(o.str());
+    }
+}
+} // namespace
+
+extern "C" int pbo_gap_graphs_run(unsigned k, long min_cov, unsigned long long n_gaps, const unsigned long long *seq_first, const unsigned long long *seq_off,
+                                  const unsigned char *codes, unsigned long long *n_nodes, unsigned long long *n_words)
+{
+    try {
+        switch (pbh::words_for_k(k)) {
+        case 1: gap_run<1>(k, min_cov, n_gaps, seq_first, seq_off, codes); break;
+        case 2: gap_run<2>(k, min_cov, n_gaps, seq_first, seq_off, codes); break;
+        case 3: gap_run<3>(k, min_cov, n_gaps, seq_first, seq_off, codes); break;
+        case 4: gap_run<4>(k, min_cov, n_gaps, seq_first, seq_off, codes); break;
+        case 5: gap_run<5>(k, min_cov, n_gaps, seq_first, seq_off, codes); break;
+        default: return -2;
+        }
+    } catch (...) { return -1; }
+    *n_nodes = g_gap.kind.size();
+    *n_words = g_gap.words.size();
+    return 0;
+}
+extern "C" void pbo_gap_graphs_fetch(unsigned long long *node_first, unsigned char *kind, unsigned short *cov, unsigned char *out, unsigned *length,
+                                     unsigned long long *word_off, unsigned long long *words)
+{
+    std::copy(g_gap.node_first.begin(), g_gap.node_first.end(), node_first);
+    std::copy(g_gap.kind.begin(), g_gap.kind.end(), kind);
+    std::copy(g_gap.cov.begin(), g_gap.cov.end(), cov);
+    std::copy(g_gap.out.begin(), g_gap.out.end(), out);
+    std::copy(g_gap.length.begin(), g_gap.length.end(), length);
+    std::copy(g_gap.word_off.begin(), g_gap.word_off.end(), word_off);
+    std::copy(g_gap.words.begin(), g_gap.words.end(), words);
+}
+// the table dump of gap g (NUL-terminated; valid until the next pbo_gap_graphs_run)
+extern "C" const char *pbo_gap_graphs_dump(unsigned long long g) { return g < g_gap.dumps.size() ? g_gap.dumps[g].c_str() : ""; }

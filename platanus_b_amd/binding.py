@@ -93,6 +93,8 @@ def load_library() -> C.CDLL:
     lib.pb_occ_lookup.argtypes = [vp, vp, vp, C.c_uint64, vp]
     lib.pb_nodes_clean_decide.argtypes = [vp, C.c_uint, C.c_uint64, vp, vp, vp, vp, vp, C.c_uint64, vp, vp, C.c_uint64, vp, vp, vp, C.c_double, C.c_uint64, C.c_uint64, vp]
     lib.pb_edit_distances.argtypes = [vp, vp, vp, C.c_uint64, vp]
+    lib.pb_gap_graphs_build.argtypes = [vp, C.c_uint, C.c_long, C.c_uint64, vp, C.c_uint64, vp, vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.pb_gap_graphs_fetch.argtypes = [vp] * 8
     _lib = lib
     return lib
 
@@ -370,6 +372,22 @@ class GpuCounter:
         d = np.zeros(max(n, 1), dtype=np.uint64)
         self._chk(self.lib.pb_edit_distances(self.h, b.ctypes.data, o.ctypes.data, n, d.ctypes.data))
         return d[:n]
+
+    def gap_graphs(self, k: int, min_cov: int, seq_first: np.ndarray, seq_off: np.ndarray, codes: np.ndarray) -> dict:
+        """pb_gap_graphs_build + _fetch: the local de Bruijn graphs of a batch of gaps (counter.h:1015-1056, graph.h:2116-2345); nodes in the
+        reference's insertion order, as arrays (node_first, kind, cov, out, length, word_off, words)."""
+        sf = np.ascontiguousarray(seq_first, dtype=np.uint64)
+        so = np.ascontiguousarray(seq_off, dtype=np.uint64)
+        cd = np.ascontiguousarray(codes, dtype=np.uint8)
+        n_gaps, n_seqs = len(sf) - 1, len(so) - 1
+        nn, nw = C.c_uint64(), C.c_uint64()
+        self._chk(self.lib.pb_gap_graphs_build(self.h, k, min_cov, n_gaps, sf.ctypes.data, n_seqs, so.ctypes.data, cd.ctypes.data, C.byref(nn), C.byref(nw)))
+        out = {"node_first": np.zeros(n_gaps + 1, dtype=np.uint64), "kind": np.zeros(nn.value, dtype=np.uint8), "cov": np.zeros(nn.value, dtype=np.uint16),
+               "out": np.zeros(nn.value, dtype=np.uint8), "length": np.zeros(nn.value, dtype=np.uint32), "word_off": np.zeros(nn.value + 1, dtype=np.uint64),
+               "words": np.zeros(max(nw.value, 1), dtype=np.uint64)}
+        self._chk(self.lib.pb_gap_graphs_fetch(self.h, *(out[n].ctypes.data for n in ("node_first", "kind", "cov", "out", "length", "word_off", "words"))))
+        out["words"] = out["words"][:nw.value]
+        return out
 
     def kernel_ms(self, stage: str) -> float:
         ms = C.c_float()

@@ -31,6 +31,23 @@ struct DevBuf {
 
 // A few persistent host threads that copy slices of a buffer (upload_bases: pageable -> pinned staging).  Starting and joining
 // threads for every 8 MB chunk cost more than the copies themselves (0.3 ms of 0.5 ms per chunk).
+// buffers and host-side bookkeeping of the batched gap-closing graphs (gap_graphs.inc)
+struct GapDesc {                     // one gap's share of the batch's arrays
+    unsigned long long slot0;        // first slot of its table
+    unsigned long long mask;         // capacity - 1
+    unsigned long long list0;        // its key list / node arrays start here (capacity = table capacity)
+    unsigned long long word0, word_cap;   // its share of the node words
+    unsigned long long scr0;         // two byte arrays of `list capacity` entries: bases collected to the right / to the left
+};
+struct PbGap {
+    DevBuf codes, seq_off, seq_gap, desc, slots, keys, n_keys, n_nodes, n_words, kind, out, cov, length, word_at, words, scr;
+    std::vector<GapDesc> h_desc;
+    unsigned long long n_gaps = 0;
+    unsigned w_out = 1;
+    std::vector<unsigned> h_n_nodes;
+    std::vector<unsigned long long> h_n_words;
+};
+
 struct CopyPool {
     std::vector<std::thread> th;
     std::mutex m;
@@ -170,6 +187,7 @@ struct pb_ctx {
     unsigned ctable_k = 0;
     DevBuf chain_work, chain_rec, chain_seq;     // K7 chain compaction
     DevBuf layout_work, layout_slots, layout_out, scan_sums, slot_blk;   // CT8 exact PREFIX_kmer_occ.bin layout
+    PbGap gap;                                                           // pb_gap_graphs_build / _fetch
     DevBuf raw_bytes, raw_work, raw_tiles, raw_s3, raw_hist;              // pb_reads_append_raw: file bytes and the per-line arrays of the device-side parse
     u64 layout_records = 0;
     u64 n_chains = 0, chain_seq_words = 0;
@@ -318,6 +336,8 @@ void pb_destroy(pb_ctx *ctx)
     release(ctx->node_work); release(ctx->node_table); release(ctx->index_table); release(ctx->node_mark); release(ctx->node_idx); release(ctx->node_rec); release(ctx->nmask_cur); release(ctx->alive); release(ctx->d_read_start);
     release(ctx->contig_packed); release(ctx->contig_mask); release(ctx->ctable);
     release(ctx->chain_work); release(ctx->chain_rec); release(ctx->chain_seq);
+    for (DevBuf *b : {&ctx->gap.codes, &ctx->gap.seq_off, &ctx->gap.seq_gap, &ctx->gap.desc, &ctx->gap.slots, &ctx->gap.keys, &ctx->gap.n_keys, &ctx->gap.n_nodes, &ctx->gap.n_words,
+                      &ctx->gap.kind, &ctx->gap.out, &ctx->gap.cov, &ctx->gap.length, &ctx->gap.word_at, &ctx->gap.words, &ctx->gap.scr}) release(*b);
     release(ctx->raw_bytes); release(ctx->raw_work); release(ctx->raw_tiles); release(ctx->raw_s3); release(ctx->raw_hist);
     release(ctx->layout_work); release(ctx->layout_slots); release(ctx->layout_out); release(ctx->scan_sums); release(ctx->slot_blk);
     for (auto &s : ctx->scratch) release(s);
@@ -1781,3 +1801,4 @@ int pb_merge_end(pb_ctx *ctx, uint64_t *occ_hist, uint64_t *max_occ, uint64_t *n
 #include "node_kernels.inc"
 #include "dist.inc"
 #include "raw_parse.inc"
+#include "gap_graphs.inc"
