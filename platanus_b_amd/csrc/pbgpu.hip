@@ -35,14 +35,15 @@ struct DevBuf {
 struct GapDesc {                     // one gap's share of the batch's arrays
     unsigned long long slot0;        // first slot of its table
     unsigned long long mask;         // capacity - 1
-    unsigned long long list0;        // its key list / node arrays start here (capacity = table capacity)
+    unsigned long long list0;        // its key list starts here (capacity = table capacity)
+    unsigned long long node0;        // its node arrays start here (capacity = its number of keys; set once the keys are counted)
     unsigned long long word0, word_cap;   // its share of the node words
-    unsigned long long scr0;         // two byte arrays of `list capacity` entries: bases collected to the right / to the left
+    unsigned long long scr0;         // two byte arrays of (keys + 1) entries: bases collected to the right / to the left
 };
 struct PbGap {
     DevBuf codes, seq_off, seq_gap, desc, slots, keys, n_keys, n_nodes, n_words, kind, out, cov, length, word_at, words, scr;
     std::vector<GapDesc> h_desc;
-    unsigned long long n_gaps = 0;
+    unsigned long long n_gaps = 0, node_cap = 0;
     unsigned w_out = 1;
     std::vector<unsigned> h_n_nodes;
     std::vector<unsigned long long> h_n_words;

@@ -129,3 +129,16 @@ def test_device_gap_graphs_many_gaps(gpu, oracle_built):
     got = gpu(0).gap_graphs(25, 2, first, off, codes)
     for field in want:
         assert np.array_equal(got[field], want[field]), field
+
+
+def test_host_mirror_of_the_gap_graphs_builds(tmp_path):
+    """platanus_b_amd/host/gap_graphs.hpp (GapBatch -> pb_gap_graphs_build / _fetch -> the reference's tables per gap) compiles against the
+    library and its table step runs without a GPU."""
+    import subprocess
+    import __graft_entry__
+    __graft_entry__.build()
+    lib_dir = os.path.join(ROOT, "platanus_b_amd")
+    exe = str(tmp_path / "gap_graphs_host")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Wno-sign-compare", "-o", exe, os.path.join(ROOT, "tests", "native", "gap_graphs_host.cpp"), "-L" + lib_dir,
+                    "-lpbgpu", "-Wl,-rpath," + lib_dir, "-Wl,-rpath-link,/opt/rocm/lib"], check=True)
+    assert subprocess.run([exe], timeout=60).returncode == 0
