@@ -270,6 +270,13 @@ int pb_edit_distances(pb_ctx *ctx, const uint8_t *bases, const uint64_t *offsets
 int pb_gap_graphs_build(pb_ctx *ctx, unsigned k, long min_coverage, uint64_t n_gaps, const uint64_t *seq_first, uint64_t n_seqs, const uint64_t *seq_off,
                         const uint8_t *codes, uint64_t *n_nodes, uint64_t *n_words);
 int pb_gap_graphs_fetch(pb_ctx *ctx, uint64_t *node_first, uint8_t *kind, uint16_t *coverage, uint8_t *out, uint32_t *length, uint64_t *word_off, uint64_t *words);
+/* mergeGraph + the graph over the merged table (gapCloseDBG.h:166-258, 424-425; BruijnGraph<KMER>::saveLargeKmerForGapClose, graph.h:2347-2370):
+ * gap g owns the straight nodes node_first[g] .. node_first[g+1]-1 IN THE ORDER in which the reference's two saveLargeKmerForGapClose calls walk
+ * them (the low graph's leftStraightTable, then the high graph's; nodes with coverage 65535 left out); node s has n_bases[s] bases (its length +
+ * its own k - 1), coverage[s] and its sequence words at word_off[s].  Every k-mer of every node goes into the gap's table with the coverage of
+ * the LAST node that holds it (setOccurrenceValueGap overwrites), then the nodes over that table as in pb_gap_graphs_build; pb_gap_graphs_fetch. */
+int pb_gap_graphs_build_from_nodes(pb_ctx *ctx, unsigned k, long min_coverage, uint64_t n_gaps, const uint64_t *node_first, uint64_t n_in, const uint32_t *n_bases,
+                                   const uint16_t *coverage, const uint64_t *word_off, const uint64_t *words, uint64_t *n_nodes, uint64_t *n_words);
 
 /* ---- multi-k rounds (assemble.cpp:392-498) ------------------------------------------------------------------- */
 /* saveEdgeKmer + pickupReadMatchedEdgeKmer (graph.h:1877-1939, counter.h:869-910): keep a read iff one of its N-free

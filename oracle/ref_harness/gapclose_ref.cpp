@@ -2,7 +2,9 @@
 // BruijnGraph<KMER>::makeBruijnGraphForGapClose (graph.h:2116-2345) on a batch of gaps and prints the tables they leave, in the tables'
 // own iteration order.  This file is ours; the reference's headers and objects are taken where they lie (oracle/Makefile, target
 // `ref`: $(REF)/*.h by -I, the objects of $(OUT)/obj without main.o) and nothing of them is copied.  Output goes to oracle/_ref/.
-// usage: gapclose_ref INPUT.bin > dump.txt
+// usage: gapclose_ref INPUT.bin > dump.txt                  the two functions at k
+//        gapclose_ref INPUT.bin K_HIGH > dump.txt           GapCloseDBG<k, K_HIGH>::gapAssemble (gapCloseDBG.h:416-436) per gap: per gap "G <index>",
+//                                                           "L", the low graph's live nodes, "H", the high graph's (same line format)
 //   INPUT.bin: u32 k, i64 min_coverage, u64 n_gaps, u64 seq_first[n_gaps + 1], u64 n_seqs, u64 seq_off[n_seqs + 1], u8 codes[] (0..3, 4 = N)
 //   dump: per gap "G <index>", then "J <key words, most significant first> <coverage> <out>" per junction and
 //         "S <length> <coverage> <out> <sequence words>" per straight node (hex), as oracle/src/capi.cpp pbo_gap_graphs_dump prints them
@@ -10,7 +12,9 @@
 #include "counter.h"
 #include "graph.h"
 #include "gapClose.h"
+#include "gapCloseDBG.h"
 #include <cstdio>
+#include <cstdlib>
 #include <cstdint>
 #include <vector>
 
@@ -52,6 +56,55 @@ static void run(unsigned k, long min_cov, const std::vector<unsigned long long> 
     }
 }
 
+template <typename KMER>
+static void dump_live(BruijnGraph<KMER> &graph, unsigned k)
+{
+    const unsigned W = (k + 31) / 32;
+    std::vector<unsigned long long> w;
+    for (auto it = graph.junctionTable.begin(); it != graph.junctionTable.end(); ++it) {
+        if (it->second.coverage == UINT16_MAX) continue;
+        key_words(it->first, W, w);
+        printf("J");
+        for (int i = (int)W - 1; i >= 0; --i) printf(" %llx", w[i]);
+        printf(" %x %x\n", (unsigned)it->second.coverage, (unsigned)it->second.out);
+    }
+    for (auto it = graph.leftStraightTable.begin(); it != graph.leftStraightTable.end(); ++it) {
+        const Straight &st = it->second;
+        if (st.coverage == UINT16_MAX) continue;
+        printf("S %llx %x %x", (unsigned long long)st.length, (unsigned)st.coverage, (unsigned)st.out);
+        const unsigned long long nb = st.length + k - 1;
+        for (unsigned long long i = 0; i < (nb + 31) / 32; ++i) {
+            unsigned long long v = i < st.seq.size() ? st.seq[i] : 0;
+            if (i == (nb + 31) / 32 - 1 && (nb % 32)) v &= ~0ull >> (64 - 2 * (nb % 32));
+            printf(" %llx", v);
+        }
+        printf("\n");
+    }
+}
+template <typename G> static void dump_width(G &e, unsigned k)
+{
+    if (k <= 32) dump_live(e.kmer31Graph, k);
+    else if (k <= 64) dump_live(e.kmer63Graph, k);
+    else if (k <= 96) dump_live(e.kmer95Graph, k);
+    else if (k <= 128) dump_live(e.kmer127Graph, k);
+    else dump_live(e.kmer159Graph, k);
+}
+template <unsigned KL, unsigned KH>
+static void run_assemble(long min_cov, const std::vector<unsigned long long> &seq_first, const std::vector<unsigned long long> &seq_off, const std::vector<unsigned char> &codes)
+{
+    for (size_t g = 0; g + 1 < seq_first.size(); ++g) {
+        GAP gap;
+        gap.seq.resize(GapClose::GAP_CANDIDATE_SEQ_1ST);
+        for (unsigned long long s = seq_first[g]; s < seq_first[g + 1]; ++s) gap.seq.push_back(std::vector<char>(codes.begin() + seq_off[s], codes.begin() + seq_off[s + 1]));
+        GapCloseDBG<KL, KH> ele(KL, KH, min_cov, 0, 0.0, &gap);
+        ele.gapAssemble();
+        printf("G %zu\nL\n", g);
+        dump_width(ele, KL);
+        printf("H\n");
+        dump_width(ele, KH);
+    }
+}
+
 int main(int argc, char **argv)
 {
     if (argc < 2) return 2;
@@ -66,6 +119,16 @@ int main(int argc, char **argv)
     std::vector<unsigned char> codes(seq_off[ns]);
     if (!codes.empty() && fread(codes.data(), 1, codes.size(), f) != codes.size()) return 3;
     fclose(f);
+    if (argc >= 3) {
+        const unsigned kh = (unsigned)atoi(argv[2]);
+        if (k == 20 && kh == 80) run_assemble<20, 80>(mc, seq_first, seq_off, codes);          // gapClose.cpp:41-42: the command's own pair
+        else if (k == 25 && kh == 60) run_assemble<25, 60>(mc, seq_first, seq_off, codes);
+        else if (k == 28 && kh == 45) run_assemble<28, 45>(mc, seq_first, seq_off, codes);
+        else if (k == 32 && kh == 100) run_assemble<32, 100>(mc, seq_first, seq_off, codes);
+        else if (k == 40 && kh == 90) run_assemble<40, 90>(mc, seq_first, seq_off, codes);
+        else return 5;
+        return 0;
+    }
     if (k <= 32) run<Kmer31>(k, mc, seq_first, seq_off, codes);
     else if (k <= 64) run<KmerN<Binstr63> >(k, mc, seq_first, seq_off, codes);
     else if (k <= 96) run<KmerN<Binstr95> >(k, mc, seq_first, seq_off, codes);

@@ -492,3 +492,59 @@ extern "C" void pbo_gap_graphs_fetch(unsigned long long *node_first, unsigned ch
 }
 // the table dump of gap g (NUL-terminated; valid until the next pbo_gap_graphs_run)
 extern "C" const char *pbo_gap_graphs_dump(unsigned long long g) { return g < g_gap.dumps.size() ? g_gap.dumps[g].c_str() : ""; }
+
+// ---- the whole graph part of a gap's assembly (gapCloseDBG.h:416-436), gap by gap: dumps of the low and the high graph ----------------------
+namespace {
+template <int W> void dump_graph(std::ostringstream &o, pbh::Graph<W> &gr, unsigned k)
+{
+    for (auto &e : gr.junctions) {
+        if (e.second.coverage == 65535) continue;
+        o << "J"; for (int w = W - 1; w >= 0; --w) o << " " << e.first.w[w]; o << " " << e.second.coverage << " " << (unsigned)e.second.out << "\n";
+    }
+    for (auto &e : gr.left) {
+        if (e.second.coverage == 65535) continue;
+        o << "S " << e.second.length << " " << e.second.coverage << " " << (unsigned)e.second.out;
+        const unsigned long long nb = e.second.length + k - 1;
+        for (unsigned long long i = 0; i < (nb + 31) / 32; ++i) {
+            unsigned long long w = i < e.second.seq.size() ? e.second.seq[i] : 0;
+            if (i == (nb + 31) / 32 - 1 && (nb % 32)) w &= ~0ull >> (64 - 2 * (nb % 32));
+            o << " " << w;
+        }
+        o << "\n";
+    }
+}
+std::vector<std::string> g_asm_dumps;
+template <int WL, int WH>
+void asm_run(unsigned kl, unsigned kh, long min_cov, unsigned long long n_gaps, const unsigned long long *seq_first, const unsigned long long *seq_off, const unsigned char *codes)
+{
+    g_asm_dumps.clear();
+    for (unsigned long long g = 0; g < n_gaps; ++g) {
+        std::vector<std::vector<unsigned char>> seqs;
+        for (unsigned long long s = seq_first[g]; s < seq_first[g + 1]; ++s) seqs.emplace_back(codes + seq_off[s], codes + seq_off[s + 1]);
+        pbh::Graph<WL> low;
+        pbh::Graph<WH> high;
+        pbo::gap_assemble<WL, WH>(seqs, kl, kh, min_cov, low, high);
+        std::ostringstream o;
+        o << std::hex << "L\n";
+        dump_graph<WL>(o, low, kl);
+        o << "H\n";
+        dump_graph<WH>(o, high, kh);
+        g_asm_dumps.push_back(o.str());
+    }
+}
+} // namespace
+extern "C" int pbo_gap_assemble_run(unsigned k_low, unsigned k_high, long min_cov, unsigned long long n_gaps, const unsigned long long *seq_first,
+                                    const unsigned long long *seq_off, const unsigned char *codes)
+{
+    const int wl = pbh::words_for_k(k_low), wh = pbh::words_for_k(k_high);
+    try {
+        if (wl == 1 && wh == 1) asm_run<1, 1>(k_low, k_high, min_cov, n_gaps, seq_first, seq_off, codes);
+        else if (wl == 1 && wh == 2) asm_run<1, 2>(k_low, k_high, min_cov, n_gaps, seq_first, seq_off, codes);
+        else if (wl == 1 && wh == 3) asm_run<1, 3>(k_low, k_high, min_cov, n_gaps, seq_first, seq_off, codes);
+        else if (wl == 1 && wh == 4) asm_run<1, 4>(k_low, k_high, min_cov, n_gaps, seq_first, seq_off, codes);
+        else if (wl == 2 && wh == 3) asm_run<2, 3>(k_low, k_high, min_cov, n_gaps, seq_first, seq_off, codes);
+        else return -2;
+    } catch (...) { return -1; }
+    return 0;
+}
+extern "C" const char *pbo_gap_assemble_dump(unsigned long long g) { return g < g_asm_dumps.size() ? g_asm_dumps[g].c_str() : ""; }

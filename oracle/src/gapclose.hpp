@@ -130,4 +130,46 @@ struct GapGraph {
     }
 };
 
+// BruijnGraph<KMER>::saveLargeKmerForGapClose (graph.h:2347-2370): the next-k-mers of every live straight node of `g` (walked in its table's
+// order), each with the node's coverage, overwriting (counter.h:194)
+template <int W, int WN>
+void save_large_kmer(Graph<W> &g, GapGraph<WN> &next)
+{
+    const unsigned nk = next.k;
+    for (auto &e : g.left) {
+        const Straight &st = e.second;
+        if (st.coverage == 65535 || st.length + g.k - 1 < nk) continue;
+        for (u64 i = 0; i + nk <= st.length + g.k - 1; ++i) {
+            Key<WN> key;
+            for (unsigned j = 0; j < nk; ++j) key.set(j, st.get(i + j));
+            next.table[key] = st.coverage;
+        }
+    }
+}
+
+// GapCloseDBG<M, N>::gapAssemble (gapCloseDBG.h:416-436) up to its last graph: low k and high k each counted, built and branch-cut
+// (assembleLowKmer / assembleHighKmer, :444-470), the high table refilled from both graphs (mergeGraph, :166-258), the high graph built again
+// from it, branch-cut and bubble-crushed.  `low` / `high` are what kmerNNGraph of either width would hold afterwards.
+template <int WL, int WH>
+void gap_assemble(const std::vector<std::vector<unsigned char>> &seqs, unsigned k_low, unsigned k_high, long min_cov, Graph<WL> &low, Graph<WH> &high)
+{
+    auto build = [&](auto &graph, auto &gg) {
+        const auto nodes = gg.make_graph(min_cov);
+        graph.delete_all();
+        for (const auto &n : nodes) { if (n.straight) graph.insert_straight(n.st); else graph.junctions[n.key] = n.jn; }
+    };
+    auto cut = [](auto &graph) { u64 n; do { n = graph.cut_branch(); graph.concatinate_nodes(); } while (n > 0); };
+    low.set_k(k_low); low.set_thresholds(0.1, 0.5);
+    high.set_k(k_high); high.set_thresholds(0.1, 0.5);
+    GapGraph<WL> cl; cl.k = k_low; cl.count(seqs);
+    build(low, cl); cut(low);
+    GapGraph<WH> ch; ch.k = k_high; ch.count(seqs);
+    build(high, ch); cut(high);
+    ch.table.clear();
+    save_large_kmer(low, ch);
+    save_large_kmer(high, ch);
+    build(high, ch); cut(high);
+    { u64 n; do { n = high.crush_bubble(65535.0); high.concatinate_nodes(); } while (n > 0); }
+}
+
 } // namespace pbo

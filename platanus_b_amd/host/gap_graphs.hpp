@@ -70,4 +70,69 @@ void gap_graph_tables(Graph<W> &gr, unsigned k, const GapNodes &r, uint64_t g)
     }
 }
 
+// ---- the graph part of GapCloseDBG<M, N>::gapAssemble (gapCloseDBG.h:416-436) for a batch of gaps -------------------------------------
+// low k and high k: counted + built on the device for all gaps at once, branch-cut per gap on the host (the node-level steps of the assemble
+// path: node_graph.hpp); mergeGraph (gapCloseDBG.h:166-258): the live straight nodes of both graphs of every gap, in the order in which the
+// reference's saveLargeKmerForGapClose calls walk them, go back to the device (pb_gap_graphs_build_from_nodes), which fills the high table
+// and builds the high graph again; branch cut and bubble crush per gap on the host.  low[g] / high[g] end up as kmerNNGraph of either width.
+struct GapNodeBatch {
+    std::vector<uint64_t> node_first{0}, word_off{0}, words;
+    std::vector<uint32_t> n_bases;
+    std::vector<uint16_t> coverage;
+    template <int W> void add_live_straights(const Graph<W> &g, unsigned next_k)
+    {
+        for (auto &e : g.left) {
+            const Straight &st = e.second;
+            if (st.coverage == 65535 || st.length + g.k - 1 < next_k) continue;      // graph.h:2359
+            n_bases.push_back((uint32_t)(st.length + g.k - 1));
+            coverage.push_back(st.coverage);
+            words.insert(words.end(), st.seq.begin(), st.seq.end());
+            for (size_t have = st.seq.size(); have < ((size_t)n_bases.back() + 31) / 32; ++have) words.push_back(0);
+            word_off.push_back(words.size());
+        }
+    }
+    void end_gap() { node_first.push_back(n_bases.size()); }
+};
+
+inline GapNodes gap_graphs_build_from_nodes(pb_ctx *ctx, unsigned k, long min_coverage, const GapNodeBatch &b)
+{
+    GapNodes r;
+    uint64_t nn = 0, nw = 0;
+    const uint64_t n_gaps = b.node_first.size() - 1;
+    int rc = pb_gap_graphs_build_from_nodes(ctx, k, min_coverage, n_gaps, b.node_first.data(), b.n_bases.size(), b.n_bases.data(), b.coverage.data(), b.word_off.data(),
+                                            b.words.data(), &nn, &nw);
+    if (rc != PB_OK) throw std::runtime_error(std::string("libpbgpu: ") + pb_last_error(ctx));
+    r.node_first.resize(n_gaps + 1); r.word_off.resize(nn + 1); r.words.resize(nw ? nw : 1);
+    r.kind.resize(nn ? nn : 1); r.out.resize(nn ? nn : 1); r.cov.resize(nn ? nn : 1); r.length.resize(nn ? nn : 1);
+    rc = pb_gap_graphs_fetch(ctx, r.node_first.data(), r.kind.data(), r.cov.data(), r.out.data(), r.length.data(), r.word_off.data(), r.words.data());
+    if (rc != PB_OK) throw std::runtime_error(std::string("libpbgpu: ") + pb_last_error(ctx));
+    return r;
+}
+
+template <int WL, int WH>
+void gap_assemble_batch(pb_ctx *ctx, unsigned k_low, unsigned k_high, long min_coverage, const GapBatch &b, std::vector<Graph<WL>> &low, std::vector<Graph<WH>> &high)
+{
+    const uint64_t n = b.n_gaps();
+    low = std::vector<Graph<WL>>(n);
+    high = std::vector<Graph<WH>>(n);
+    auto cut = [](auto &g) { u64 d; do { d = g.cut_branch(); g.concatinate_nodes(); } while (d > 0); };     // gapCloseDBG.h:450-453
+    {
+        const GapNodes nl = gap_graphs_build(ctx, k_low, min_coverage, b);                                 // assembleLowKmer
+        for (uint64_t g = 0; g < n; ++g) { low[g].set_thresholds(0.1, 0.5); gap_graph_tables<WL>(low[g], k_low, nl, g); cut(low[g]); }
+    }
+    {
+        const GapNodes nh = gap_graphs_build(ctx, k_high, min_coverage, b);                                // assembleHighKmer
+        for (uint64_t g = 0; g < n; ++g) { high[g].set_thresholds(0.1, 0.5); gap_graph_tables<WH>(high[g], k_high, nh, g); cut(high[g]); }
+    }
+    GapNodeBatch nb;                                                                                       // mergeGraph
+    for (uint64_t g = 0; g < n; ++g) { nb.add_live_straights(low[g], k_high); nb.add_live_straights(high[g], k_high); nb.end_gap(); }
+    const GapNodes nm = gap_graphs_build_from_nodes(ctx, k_high, min_coverage, nb);                        // highKmerMakeBruijnGraph on the merged table
+    for (uint64_t g = 0; g < n; ++g) {
+        gap_graph_tables<WH>(high[g], k_high, nm, g);                                                      // (the same Graph object: clear() keeps its bucket array, as the reference's does)
+        cut(high[g]);
+        u64 d;
+        do { d = high[g].crush_bubble(65535.0); high[g].concatinate_nodes(); } while (d > 0);              // gapCloseDBG.h:431-434
+    }
+}
+
 } // namespace pbh

@@ -47,3 +47,15 @@ def make_gaps(name):
         first.insert(3, first[2])
     off = np.concatenate([[0], np.cumsum([len(s) for s in seqs])]).astype(np.uint64)
     return k, mc, np.array(first, dtype=np.uint64), off, np.concatenate(seqs)
+
+
+# (k_low, k_high, min_coverage, case whose gaps are used): GapCloseDBG<k_low, k_high>::gapAssemble; (20, 80) is gap_close's own pair
+# (gapClose.cpp:41-43: BRUIJN_MIN_KMER, BRUIJN_MAX_KMER, MIN_COVERAGE = 2)
+ASSEMBLE_CASES = {
+    "asm_20_80": (20, 80, 2, "k100_c2"),
+    "asm_20_80_b": (20, 80, 2, "k75_c2"),
+    "asm_25_60": (25, 60, 2, "k45_c2"),
+    "asm_28_45": (28, 45, 2, "k31_c3_deep"),
+    "asm_32_100": (32, 100, 2, "k100_c2"),
+    "asm_40_90": (40, 90, 3, "k75_c2"),
+}

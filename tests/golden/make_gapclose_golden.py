@@ -19,3 +19,11 @@ for name in gapclose_cases.CASES:
         for g, d in enumerate(dumps):
             f.write(f"G {g}\n{d}")
     print(name, "k", k, "gaps", len(dumps), "lines", sum(d.count("\n") for d in dumps))
+
+for name, (kl, kh, mc, case) in gapclose_cases.ASSEMBLE_CASES.items():
+    k, _, first, off, codes = gapclose_cases.make_gaps(case)
+    dumps = pyoracle.gap_assemble_reference(kl, kh, mc, first, off, codes)          # GapCloseDBG<kl, kh>::gapAssemble of the reference itself
+    with open(os.path.join(out_dir, name + ".txt"), "w") as f:
+        for g, d in enumerate(dumps):
+            f.write(f"G {g}\n{d}")
+    print(name, "gaps", len(dumps), "lines", sum(d.count("\n") for d in dumps))

@@ -1,0 +1,71 @@
+// The graph part of a gap's assembly through the product: platanus_b_amd/host/gap_graphs.hpp gap_assemble_batch (device: counting, graph
+// construction, merged table; host: the node-level cleaning) on the input format of oracle/ref_harness/gapclose_ref.cpp, printed in that
+// harness's format -- so that its output can be compared with dumps of the reference's own GapCloseDBG<M, N>::gapAssemble tables.
+// usage: gap_assemble_host INPUT.bin K_HIGH > dump.txt      (needs a GPU)
+#include "../../platanus_b_amd/host/gap_graphs.hpp"
+#include <cstdio>
+#include <cstdlib>
+
+template <int W> static void dump(pbh::Graph<W> &gr, unsigned k)
+{
+    for (auto &e : gr.junctions) {
+        if (e.second.coverage == 65535) continue;
+        printf("J");
+        for (int w = W - 1; w >= 0; --w) printf(" %llx", (unsigned long long)e.first.w[w]);
+        printf(" %x %x\n", (unsigned)e.second.coverage, (unsigned)e.second.out);
+    }
+    for (auto &e : gr.left) {
+        if (e.second.coverage == 65535) continue;
+        printf("S %llx %x %x", (unsigned long long)e.second.length, (unsigned)e.second.coverage, (unsigned)e.second.out);
+        const unsigned long long nb = e.second.length + k - 1;
+        for (unsigned long long i = 0; i < (nb + 31) / 32; ++i) {
+            unsigned long long w = i < e.second.seq.size() ? e.second.seq[i] : 0;
+            if (i == (nb + 31) / 32 - 1 && (nb % 32)) w &= ~0ull >> (64 - 2 * (nb % 32));
+            printf(" %llx", w);
+        }
+        printf("\n");
+    }
+}
+template <int WL, int WH> static void run(pb_ctx *ctx, unsigned kl, unsigned kh, long mc, const pbh::GapBatch &b)
+{
+    std::vector<pbh::Graph<WL>> low;
+    std::vector<pbh::Graph<WH>> high;
+    pbh::gap_assemble_batch<WL, WH>(ctx, kl, kh, mc, b, low, high);
+    for (size_t g = 0; g < low.size(); ++g) {
+        printf("G %zu\nL\n", g);
+        dump<WL>(low[g], kl);
+        printf("H\n");
+        dump<WH>(high[g], kh);
+    }
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 3) return 2;
+    FILE *f = fopen(argv[1], "rb");
+    if (!f) return 2;
+    uint32_t k = 0; int64_t mc = 0; uint64_t ng = 0, ns = 0;
+    if (fread(&k, 4, 1, f) != 1 || fread(&mc, 8, 1, f) != 1 || fread(&ng, 8, 1, f) != 1) return 3;
+    std::vector<uint64_t> seq_first(ng + 1);
+    if (fread(seq_first.data(), 8, ng + 1, f) != ng + 1 || fread(&ns, 8, 1, f) != 1) return 3;
+    std::vector<uint64_t> seq_off(ns + 1);
+    if (fread(seq_off.data(), 8, ns + 1, f) != ns + 1) return 3;
+    std::vector<uint8_t> codes(seq_off[ns]);
+    if (!codes.empty() && fread(codes.data(), 1, codes.size(), f) != codes.size()) return 3;
+    fclose(f);
+    pbh::GapBatch b;
+    b.seq_first = seq_first; b.seq_off = seq_off; b.codes = codes;
+    const unsigned kh = (unsigned)atoi(argv[2]);
+    pb_ctx *ctx = nullptr;
+    if (pb_create(0, &ctx) != PB_OK) { fprintf(stderr, "%s\n", pb_last_error(nullptr)); return 4; }
+    try {
+        const int wl = pbh::words_for_k(k), wh = pbh::words_for_k(kh);
+        if (wl == 1 && wh == 2) run<1, 2>(ctx, k, kh, mc, b);
+        else if (wl == 1 && wh == 3) run<1, 3>(ctx, k, kh, mc, b);
+        else if (wl == 1 && wh == 4) run<1, 4>(ctx, k, kh, mc, b);
+        else if (wl == 2 && wh == 3) run<2, 3>(ctx, k, kh, mc, b);
+        else { fprintf(stderr, "no instantiation for this pair of k\n"); return 5; }
+    } catch (const std::exception &e) { fprintf(stderr, "%s\n", e.what()); pb_destroy(ctx); return 6; }
+    pb_destroy(ctx);
+    return 0;
+}

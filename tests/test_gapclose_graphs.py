@@ -142,3 +142,58 @@ def test_host_mirror_of_the_gap_graphs_builds(tmp_path):
     subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Wno-sign-compare", "-o", exe, os.path.join(ROOT, "tests", "native", "gap_graphs_host.cpp"), "-L" + lib_dir,
                     "-lpbgpu", "-Wl,-rpath," + lib_dir, "-Wl,-rpath-link,/opt/rocm/lib"], check=True)
     assert subprocess.run([exe], timeout=60).returncode == 0
+
+
+@pytest.mark.parametrize("name", sorted(gapclose_cases.ASSEMBLE_CASES))
+def test_oracle_gap_assembly_against_the_reference_tables(name, oracle_built):
+    """The graph part of GapCloseDBG<M, N>::gapAssemble (gapCloseDBG.h:416-436: low k and high k counted, built and branch-cut, mergeGraph =
+    saveLargeKmerForGapClose of both graphs into the high table, the high graph built again, branch cut, bubble crush): the restatement's
+    low and high tables must be the reference's own, node for node in iteration order (dumps of GapCloseDBG's tables, incl. gap_close's
+    own pair k = 20 / 80)."""
+    from oracle import pyoracle
+    kl, kh, mc, case = gapclose_cases.ASSEMBLE_CASES[name]
+    _, _, first, off, codes = gapclose_cases.make_gaps(case)
+    dumps = pyoracle.gap_assemble(kl, kh, mc, first, off, codes)
+    gold = _golden(name)
+    assert len(dumps) == len(gold)
+    for g, (a, b) in enumerate(zip(dumps, gold)):
+        assert a == b, f"{name}: graphs of gap {g} differ from the reference's"
+    assert sum(d.count("\nS ") for d in gold) > 0
+
+
+@pytest.fixture(scope="module")
+def gap_assemble_host(tmp_path_factory):
+    import subprocess
+    import __graft_entry__
+    __graft_entry__.build()
+    lib_dir = os.path.join(ROOT, "platanus_b_amd")
+    exe = str(tmp_path_factory.mktemp("native") / "gap_assemble_host")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-Wno-sign-compare", "-o", exe, os.path.join(ROOT, "tests", "native", "gap_assemble_host.cpp"), "-L" + lib_dir,
+                    "-lpbgpu", "-lpthread", "-Wl,-rpath," + lib_dir, "-Wl,-rpath-link,/opt/rocm/lib"], check=True)
+    return exe
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(gapclose_cases.ASSEMBLE_CASES))
+def test_device_gap_assembly_against_the_reference_tables(name, gap_assemble_host, tmp_path):
+    """The same through the product: host/gap_graphs.hpp gap_assemble_batch -- pb_gap_graphs_build at both k for all gaps at once, the
+    node-level cleaning on the host, pb_gap_graphs_build_from_nodes for the merged table -- must leave the reference's tables."""
+    import struct
+    import subprocess
+    from oracle import pyoracle
+    kl, kh, mc, case = gapclose_cases.ASSEMBLE_CASES[name]
+    _, _, first, off, codes = gapclose_cases.make_gaps(case)
+    inp = tmp_path / "gaps.bin"
+    with open(inp, "wb") as f:
+        f.write(struct.pack("<IqQ", kl, mc, len(first) - 1))
+        f.write(first.tobytes())
+        f.write(struct.pack("<Q", len(off) - 1))
+        f.write(off.tobytes())
+        f.write(codes[:int(off[-1])].tobytes())
+    p = subprocess.run([gap_assemble_host, str(inp), str(kh)], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    got = pyoracle.split_gap_dump(p.stdout)
+    gold = _golden(name)
+    assert len(got) == len(gold)
+    for g, (a, b) in enumerate(zip(got, gold)):
+        assert a == b, f"{name}: graphs of gap {g} differ from the reference's"
