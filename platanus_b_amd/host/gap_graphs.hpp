@@ -5,7 +5,10 @@
 // them in that order into tables with the reference's hashers (node_graph.hpp: Graph<W>) gives tables that iterate as the reference's do.
 #pragma once
 #include "node_graph.hpp"
+#include <algorithm>
+#include <exception>
 #include <stdexcept>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -116,23 +119,36 @@ void gap_assemble_batch(pb_ctx *ctx, unsigned k_low, unsigned k_high, long min_c
     low = std::vector<Graph<WL>>(n);
     high = std::vector<Graph<WH>>(n);
     auto cut = [](auto &g) { u64 d; do { d = g.cut_branch(); g.concatinate_nodes(); } while (d > 0); };     // gapCloseDBG.h:450-453
+    // the per-gap host steps: gaps are independent of each other (their own tables), so they are spread over host threads
+    auto for_gaps = [&](auto &&body) {
+        const unsigned nt = (unsigned)std::min<uint64_t>(std::max(1u, std::min(16u, std::thread::hardware_concurrency())), std::max<uint64_t>(n / 64, 1));
+        std::vector<std::exception_ptr> err(nt);
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; ++t)
+            th.emplace_back([&, t]() {
+                try { for (uint64_t g = n * t / nt; g < n * (t + 1) / nt; ++g) body(g); }
+                catch (...) { err[t] = std::current_exception(); }
+            });
+        for (auto &x : th) x.join();
+        for (auto &e : err) if (e) std::rethrow_exception(e);
+    };
     {
         const GapNodes nl = gap_graphs_build(ctx, k_low, min_coverage, b);                                 // assembleLowKmer
-        for (uint64_t g = 0; g < n; ++g) { low[g].set_thresholds(0.1, 0.5); gap_graph_tables<WL>(low[g], k_low, nl, g); cut(low[g]); }
+        for_gaps([&](uint64_t g) { low[g].set_thresholds(0.1, 0.5); gap_graph_tables<WL>(low[g], k_low, nl, g); cut(low[g]); });
     }
     {
         const GapNodes nh = gap_graphs_build(ctx, k_high, min_coverage, b);                                // assembleHighKmer
-        for (uint64_t g = 0; g < n; ++g) { high[g].set_thresholds(0.1, 0.5); gap_graph_tables<WH>(high[g], k_high, nh, g); cut(high[g]); }
+        for_gaps([&](uint64_t g) { high[g].set_thresholds(0.1, 0.5); gap_graph_tables<WH>(high[g], k_high, nh, g); cut(high[g]); });
     }
     GapNodeBatch nb;                                                                                       // mergeGraph
     for (uint64_t g = 0; g < n; ++g) { nb.add_live_straights(low[g], k_high); nb.add_live_straights(high[g], k_high); nb.end_gap(); }
     const GapNodes nm = gap_graphs_build_from_nodes(ctx, k_high, min_coverage, nb);                        // highKmerMakeBruijnGraph on the merged table
-    for (uint64_t g = 0; g < n; ++g) {
+    for_gaps([&](uint64_t g) {
         gap_graph_tables<WH>(high[g], k_high, nm, g);                                                      // (the same Graph object: clear() keeps its bucket array, as the reference's does)
         cut(high[g]);
         u64 d;
         do { d = high[g].crush_bubble(65535.0); high[g].concatinate_nodes(); } while (d > 0);              // gapCloseDBG.h:431-434
-    }
+    });
 }
 
 } // namespace pbh

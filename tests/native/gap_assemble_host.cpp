@@ -2,9 +2,12 @@
 // construction, merged table; host: the node-level cleaning) on the input format of oracle/ref_harness/gapclose_ref.cpp, printed in that
 // harness's format -- so that its output can be compared with dumps of the reference's own GapCloseDBG<M, N>::gapAssemble tables.
 // usage: gap_assemble_host INPUT.bin K_HIGH > dump.txt      (needs a GPU)
+//        gap_assemble_host INPUT.bin K_HIGH time            no dump: wall time of gap_assemble_batch and the nodes left, one line
 #include "../../platanus_b_amd/host/gap_graphs.hpp"
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 template <int W> static void dump(pbh::Graph<W> &gr, unsigned k)
 {
@@ -26,11 +29,22 @@ template <int W> static void dump(pbh::Graph<W> &gr, unsigned k)
         printf("\n");
     }
 }
+static bool g_time_only = false;
 template <int WL, int WH> static void run(pb_ctx *ctx, unsigned kl, unsigned kh, long mc, const pbh::GapBatch &b)
 {
     std::vector<pbh::Graph<WL>> low;
     std::vector<pbh::Graph<WH>> high;
+    const auto t0 = std::chrono::steady_clock::now();
     pbh::gap_assemble_batch<WL, WH>(ctx, kl, kh, mc, b, low, high);
+    if (g_time_only) {
+        const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        unsigned long long nodes = 0;
+        for (auto &g : high) for (auto &e : g.left) nodes += e.second.coverage != 65535;
+        float ms = 0;
+        (void)pb_last_kernel_ms(ctx, "gap_graphs", &ms);
+        printf("{\"gaps\": %zu, \"k_low\": %u, \"k_high\": %u, \"gap_assemble_batch_s\": %.3f, \"last_device_call_kernels_ms\": %.1f, \"straight_nodes_left\": %llu}\n", low.size(), kl, kh, s, ms, nodes);
+        return;
+    }
     for (size_t g = 0; g < low.size(); ++g) {
         printf("G %zu\nL\n", g);
         dump<WL>(low[g], kl);
@@ -56,6 +70,7 @@ int main(int argc, char **argv)
     pbh::GapBatch b;
     b.seq_first = seq_first; b.seq_off = seq_off; b.codes = codes;
     const unsigned kh = (unsigned)atoi(argv[2]);
+    g_time_only = argc >= 4 && !strcmp(argv[3], "time");
     pb_ctx *ctx = nullptr;
     if (pb_create(0, &ctx) != PB_OK) { fprintf(stderr, "%s\n", pb_last_error(nullptr)); return 4; }
     try {
