@@ -43,6 +43,7 @@ struct GapDesc {                     // one gap's share of the batch's arrays
 struct PbGap {
     DevBuf codes, seq_off, seq_gap, desc, slots, keys, n_keys, n_nodes, n_words, kind, out, cov, length, word_at, words, scr;
     DevBuf in_words, in_word_off, in_bases, in_order, in_cov, in_node_first, slot_first;      // pb_gap_graphs_build_from_nodes
+    DevBuf pk_to, pk_bytes, pk_cov, pk_len, pk_woff, pk_words;                               // pb_gap_graphs_fetch: the packed result
     std::vector<GapDesc> h_desc;
     unsigned long long n_gaps = 0, node_cap = 0;
     unsigned w_out = 1;
@@ -340,7 +341,8 @@ void pb_destroy(pb_ctx *ctx)
     release(ctx->chain_work); release(ctx->chain_rec); release(ctx->chain_seq);
     for (DevBuf *b : {&ctx->gap.codes, &ctx->gap.seq_off, &ctx->gap.seq_gap, &ctx->gap.desc, &ctx->gap.slots, &ctx->gap.keys, &ctx->gap.n_keys, &ctx->gap.n_nodes, &ctx->gap.n_words,
                       &ctx->gap.kind, &ctx->gap.out, &ctx->gap.cov, &ctx->gap.length, &ctx->gap.word_at, &ctx->gap.words, &ctx->gap.scr, &ctx->gap.in_words, &ctx->gap.in_word_off,
-                      &ctx->gap.in_bases, &ctx->gap.in_order, &ctx->gap.in_cov, &ctx->gap.in_node_first, &ctx->gap.slot_first}) release(*b);
+                      &ctx->gap.in_bases, &ctx->gap.in_order, &ctx->gap.in_cov, &ctx->gap.in_node_first, &ctx->gap.slot_first, &ctx->gap.pk_to, &ctx->gap.pk_bytes, &ctx->gap.pk_cov,
+                      &ctx->gap.pk_len, &ctx->gap.pk_woff, &ctx->gap.pk_words}) release(*b);
     release(ctx->raw_bytes); release(ctx->raw_work); release(ctx->raw_tiles); release(ctx->raw_s3); release(ctx->raw_hist);
     release(ctx->layout_work); release(ctx->layout_slots); release(ctx->layout_out); release(ctx->scan_sums); release(ctx->slot_blk);
     for (auto &s : ctx->scratch) release(s);
