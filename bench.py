@@ -19,7 +19,8 @@ Reads are packed on the device before the timed region (inputs resident in HBM).
 from its own progress lines; falls back to the repo's CPU port when the binary did not travel),
 `end_to_end` (the drop-in CLI on the same FASTQ files, outputs checked against the reference's md5s) and
 `shard_shapes` (the counting pass on what one of the 8 GPUs of configs[3] and configs[4] holds, and the bench
-workload at k = 45 and k = 75: the two-word and three-word variants of the pass beside the direct pass).
+workload at k = 45 and k = 75: the two-word and three-word variants of the pass beside the direct pass; the batched
+gap-closing graphs of SURVEY 8(f) row 4 on synthetic gaps, checked against their CPU restatement).
 """
 import argparse
 import json
@@ -245,6 +246,47 @@ def shard_shapes():
     return out
 
 
+def gap_graphs_leg(n_gaps=4000):
+    """SURVEY 8(f) row 4 beside the headline (N = 1, in the child process of the shard shapes): the batched gap-closing graphs on synthetic
+    gaps (200-1500 bp, 20x of 150-base reads, 1 % errors), k = 32 and gap_close's own k = 20 / 80 pair's high k; the CPU restatement of the
+    same two functions (oracle, one thread) is this leg's CPU baseline and its checker."""
+    import time
+    from oracle import pyoracle
+    from platanus_b_amd.binding import GpuCounter
+    rng = np.random.default_rng(9)
+    seqs, first = [], [0]
+    for _ in range(n_gaps):
+        G = int(rng.integers(200, 1500))
+        genome = rng.integers(0, 4, G).astype(np.uint8)
+        for _ in range(max(1, G * 20 // 150)):
+            L = min(150, G)
+            s = int(rng.integers(0, G - L + 1))
+            r = genome[s:s + L].copy()
+            e = rng.random(L) < 0.01
+            r[e] = (r[e] + 1) & 3
+            seqs.append(r)
+        first.append(len(seqs))
+    off = np.concatenate([[0], np.cumsum([len(s) for s in seqs])]).astype(np.uint64)
+    codes = np.concatenate(seqs)
+    first = np.array(first, dtype=np.uint64)
+    g = GpuCounter(0)
+    out = {"gaps": n_gaps, "sequences": len(seqs), "bases": int(off[-1]), "min_coverage": 2}
+    for k in (32, 80):
+        g.gap_graphs(k, 2, first[:3], off[:int(first[2]) + 1], codes)              # (module load, first allocations)
+        t0 = time.perf_counter()
+        got = g.gap_graphs(k, 2, first, off, codes)
+        t_dev = time.perf_counter() - t0
+        k_ms = g.kernel_ms("gap_graphs")
+        t0 = time.perf_counter()
+        want, _ = pyoracle.gap_graphs(k, 2, first, off, codes)
+        t_cpu = time.perf_counter() - t0
+        out[f"k{k}"] = {"nodes": int(len(want["kind"])), "device_call_s": t_dev, "device_kernels_ms": k_ms,
+                        "cpu_baseline": {"kind": "port", "cores": 1, "seconds": t_cpu, "sample": "the same batch, oracle/src/gapclose.hpp"},
+                        "identical_to_cpu_baseline": bool(all(np.array_equal(got[f], want[f]) for f in want))}
+    g.close()
+    return out
+
+
 def self_launch(n):
     """Start the ranks of an N-GPU run: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
     --master-port P bench.py <the same arguments>` as a child process; returns its exit status."""
@@ -274,7 +316,12 @@ def main():
     ap.add_argument("--self-launch", action="store_true", help=argparse.SUPPRESS)                 # tests: take the N > 1 launch path with --gpus 1
     a = ap.parse_args()
     if a.shard_shapes_only:
-        print(json.dumps(shard_shapes()))
+        res = shard_shapes()
+        try:
+            res["gap_graphs (SURVEY 8(f) row 4)"] = gap_graphs_leg()
+        except Exception as e:
+            res["gap_graphs (SURVEY 8(f) row 4)"] = {"error": str(e)}
+        print(json.dumps(res))
         return
     if a.gpus < 1:
         sys.exit("bench.py: --gpus must be >= 1")
