@@ -217,24 +217,24 @@ def split_gap_dump(text: str):
     return dumps
 
 
-def gap_assemble(k_low: int, k_high: int, min_cov: int, seq_first: np.ndarray, seq_off: np.ndarray, codes: np.ndarray):
+def gap_assemble(k_low: int, k_high: int, min_cov: int, seq_first: np.ndarray, seq_off: np.ndarray, codes: np.ndarray, flanks: bytes = None):
     """gapclose.hpp gap_assemble(): the graph part of GapCloseDBG<M, N>::gapAssemble (gapCloseDBG.h:416-436) gap by gap; per gap the dump
     "L\\n<low graph's live nodes>H\\n<high graph's>" in the tables' iteration order."""
     L = lib()
-    L.pbo_gap_assemble_run.argtypes = [C.c_uint, C.c_uint, C.c_long, C.c_ulonglong, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.pbo_gap_assemble_run.argtypes = [C.c_uint, C.c_uint, C.c_long, C.c_ulonglong, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p]
     L.pbo_gap_assemble_dump.argtypes = [C.c_ulonglong]
     L.pbo_gap_assemble_dump.restype = C.c_char_p
     seq_first = np.ascontiguousarray(seq_first, dtype=np.uint64)
     seq_off = np.ascontiguousarray(seq_off, dtype=np.uint64)
     codes = np.ascontiguousarray(codes, dtype=np.uint8)
     n_gaps = len(seq_first) - 1
-    rc = L.pbo_gap_assemble_run(k_low, k_high, min_cov, n_gaps, seq_first.ctypes.data, seq_off.ctypes.data, codes.ctypes.data)
+    rc = L.pbo_gap_assemble_run(k_low, k_high, min_cov, n_gaps, seq_first.ctypes.data, seq_off.ctypes.data, codes.ctypes.data, flanks)
     if rc != 0:
         raise RuntimeError(f"pbo_gap_assemble_run: {rc}")
     return [L.pbo_gap_assemble_dump(g).decode() for g in range(n_gaps)]
 
 
-def gap_assemble_reference(k_low: int, k_high: int, min_cov: int, seq_first: np.ndarray, seq_off: np.ndarray, codes: np.ndarray):
+def gap_assemble_reference(k_low: int, k_high: int, min_cov: int, seq_first: np.ndarray, seq_off: np.ndarray, codes: np.ndarray, flanks: bytes = None):
     """The same from the REFERENCE's own GapCloseDBG<k_low, k_high>::gapAssemble (oracle/_ref/gapclose_ref INPUT K_HIGH; the pairs the harness
     instantiates: (20, 80) -- the command's own --, (25, 60), (28, 45), (32, 100), (40, 90))."""
     import struct
@@ -250,7 +250,16 @@ def gap_assemble_reference(k_low: int, k_high: int, min_cov: int, seq_first: np.
         f.write(seq_off.tobytes())
         f.write(codes[:int(seq_off[-1])].tobytes())
         f.flush()
-        p = subprocess.run([exe, f.name, str(k_high)], capture_output=True, text=True, timeout=900)
+        args = [exe, f.name, str(k_high)]
+        ff = None
+        if flanks is not None:
+            ff = tempfile.NamedTemporaryFile(suffix=".flanks")
+            ff.write(flanks)
+            ff.flush()
+            args.append(ff.name)
+        p = subprocess.run(args, capture_output=True, text=True, timeout=900)
+        if ff is not None:
+            ff.close()
     if p.returncode != 0:
         raise RuntimeError(f"gapclose_ref: {p.returncode} {p.stderr[-500:]}")
     return split_gap_dump(p.stdout)

@@ -5,6 +5,10 @@
 // usage: gapclose_ref INPUT.bin > dump.txt                  the two functions at k
 //        gapclose_ref INPUT.bin K_HIGH > dump.txt           GapCloseDBG<k, K_HIGH>::gapAssemble (gapCloseDBG.h:416-436) per gap: per gap "G <index>",
 //                                                           "L", the low graph's live nodes, "H", the high graph's (same line format)
+//        gapclose_ref INPUT.bin K_HIGH FLANKS.bin > dump.txt  ... and what the reference then decides about the gap (gapClose.cpp:716-760 without
+//                                                           the OLC fallback; -vd 32, -ed 0.01): FLANKS.bin per gap: i32 start, i32 end, u8 at a
+//                                                           scaffold's end, u32 head length, u32 tail length, head codes, tail codes; lines
+//                                                           "X" (not enabled) | "C closed seqLength bases.." [+ "P closed seqLength remainedGap bases.."] | "E .."
 //   INPUT.bin: u32 k, i64 min_coverage, u64 n_gaps, u64 seq_first[n_gaps + 1], u64 n_seqs, u64 seq_off[n_seqs + 1], u8 codes[] (0..3, 4 = N)
 //   dump: per gap "G <index>", then "J <key words, most significant first> <coverage> <out>" per junction and
 //         "S <length> <coverage> <out> <sequence words>" per straight node (hex), as oracle/src/capi.cpp pbo_gap_graphs_dump prints them
@@ -89,6 +93,14 @@ template <typename G> static void dump_width(G &e, unsigned k)
     else if (k <= 128) dump_live(e.kmer127Graph, k);
     else dump_live(e.kmer159Graph, k);
 }
+static FILE *g_flanks = NULL;
+static void print_seq(const char *tag, bool ok, int len, int remained, const std::vector<char> &seq, bool with_remained)
+{
+    printf("%s %d %d", tag, ok ? 1 : 0, ok ? len : 0);                   // (what a failed attempt leaves in seqLength is not part of the result)
+    if (with_remained) printf(" %d", ok ? remained : 0);
+    for (size_t i = 0; i < seq.size(); ++i) printf(" %d", (int)seq[i]);
+    printf("\n");
+}
 template <unsigned KL, unsigned KH>
 static void run_assemble(long min_cov, const std::vector<unsigned long long> &seq_first, const std::vector<unsigned long long> &seq_off, const std::vector<unsigned char> &codes)
 {
@@ -96,12 +108,34 @@ static void run_assemble(long min_cov, const std::vector<unsigned long long> &se
         GAP gap;
         gap.seq.resize(GapClose::GAP_CANDIDATE_SEQ_1ST);
         for (unsigned long long s = seq_first[g]; s < seq_first[g + 1]; ++s) gap.seq.push_back(std::vector<char>(codes.begin() + seq_off[s], codes.begin() + seq_off[s + 1]));
-        GapCloseDBG<KL, KH> ele(KL, KH, min_cov, 0, 0.0, &gap);
+        bool at_end = false;
+        if (g_flanks) {
+            int32_t se[2]; uint8_t e; uint32_t hl, tl;
+            if (fread(se, 4, 2, g_flanks) != 2 || fread(&e, 1, 1, g_flanks) != 1 || fread(&hl, 4, 1, g_flanks) != 1 || fread(&tl, 4, 1, g_flanks) != 1) exit(7);
+            gap.start = se[0]; gap.end = se[1]; at_end = e != 0;
+            gap.headSeq.resize(hl); gap.tailSeq.resize(tl);
+            if ((hl && fread(gap.headSeq.data(), 1, hl, g_flanks) != hl) || (tl && fread(gap.tailSeq.data(), 1, tl, g_flanks) != tl)) exit(7);
+        }
+        GapCloseDBG<KL, KH> ele(KL, KH, min_cov, 32, 0.01, &gap);          // gapClose.cpp:57,60: -vd 32, -ed 0.01
+        printf("G %zu\n", g);
+        if (g_flanks && !at_end && !ele.enableGapClose()) { printf("X\n"); continue; }      // gapClose.cpp:716-717
         ele.gapAssemble();
-        printf("G %zu\nL\n", g);
+        printf("L\n");
         dump_width(ele, KL);
         printf("H\n");
         dump_width(ele, KH);
+        if (!g_flanks) continue;
+        if (!at_end) {
+            const bool closed = ele.isClosedGap();
+            print_seq("C", closed, ele.getSeqLength(), 0, closed ? ele.getSeq() : std::vector<char>(), false);
+            if (!closed) {                                                    // gapClose.cpp:743-751 (-no_partial off)
+                const bool part = ele.isClosedGapPartial();
+                print_seq("P", part, ele.getSeqLength(), ele.getRemainedGap(), part ? ele.getSeq() : std::vector<char>(), true);
+            }
+        } else {
+            const bool ext = ele.extendEdge();                                // gapClose.cpp:754-760
+            print_seq("E", ext, ele.getSeqLength(), 0, ext ? ele.getSeq() : std::vector<char>(), false);
+        }
     }
 }
 
@@ -121,6 +155,7 @@ int main(int argc, char **argv)
     fclose(f);
     if (argc >= 3) {
         const unsigned kh = (unsigned)atoi(argv[2]);
+        if (argc >= 4 && !(g_flanks = fopen(argv[3], "rb"))) return 2;
         if (k == 20 && kh == 80) run_assemble<20, 80>(mc, seq_first, seq_off, codes);          // gapClose.cpp:41-42: the command's own pair
         else if (k == 25 && kh == 60) run_assemble<25, 60>(mc, seq_first, seq_off, codes);
         else if (k == 28 && kh == 45) run_assemble<28, 45>(mc, seq_first, seq_off, codes);

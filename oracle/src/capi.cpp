@@ -407,6 +407,7 @@ extern "C" int pbo_parse_file_check(const char *path, unsigned max_threads, unsi
 
 // ---- local de Bruijn graphs of gap closing (gapclose.hpp): a batch of gaps, nodes in the reference's insertion order ---------------------
 #include "gapclose.hpp"
+#include "../../platanus_b_amd/host/gap_graphs.hpp"
 #include <sstream>
 namespace {
 struct GapResult {
@@ -514,35 +515,77 @@ template <int W> void dump_graph(std::ostringstream &o, pbh::Graph<W> &gr, unsig
     }
 }
 std::vector<std::string> g_asm_dumps;
+// flanks (optional): per gap i32 start, i32 end, u8 at a scaffold's end, u32 head length, u32 tail length, head codes, tail codes
+struct FlankReader {
+    const unsigned char *p = nullptr;
+    bool next(pbh::GapFlanks &f, bool &at_end)
+    {
+        if (!p) return false;
+        int32_t se[2]; uint32_t hl, tl;
+        memcpy(se, p, 8); at_end = p[8] != 0; memcpy(&hl, p + 9, 4); memcpy(&tl, p + 13, 4);
+        p += 17;
+        f.start = se[0]; f.end = se[1];
+        f.head.assign((const char *)p, (const char *)p + hl); p += hl;
+        f.tail.assign((const char *)p, (const char *)p + tl); p += tl;
+        return true;
+    }
+};
+void closure_line(std::ostringstream &o, const char *tag, bool ok, const pbh::GapClosure &c, bool with_remained)
+{
+    o << std::dec << tag << " " << (ok ? 1 : 0) << " " << (ok ? c.seq_length : 0);
+    if (with_remained) o << " " << (ok ? c.remained_gap : 0);
+    if (ok) for (char b : c.seq) o << " " << (int)b;
+    o << "\n";
+}
 template <int WL, int WH>
-void asm_run(unsigned kl, unsigned kh, long min_cov, unsigned long long n_gaps, const unsigned long long *seq_first, const unsigned long long *seq_off, const unsigned char *codes)
+void asm_run(unsigned kl, unsigned kh, long min_cov, unsigned long long n_gaps, const unsigned long long *seq_first, const unsigned long long *seq_off, const unsigned char *codes,
+             const unsigned char *flanks)
 {
     g_asm_dumps.clear();
+    FlankReader fr{flanks};
     for (unsigned long long g = 0; g < n_gaps; ++g) {
         std::vector<std::vector<unsigned char>> seqs;
         for (unsigned long long s = seq_first[g]; s < seq_first[g + 1]; ++s) seqs.emplace_back(codes + seq_off[s], codes + seq_off[s + 1]);
+        pbh::GapFlanks fl;
+        bool at_end = false;
+        const bool have_flanks = fr.next(fl, at_end);
+        pbh::GapCloser cl;
+        cl.max_k = kh; cl.gap = &fl;
+        std::ostringstream o;
+        if (have_flanks && !at_end && !cl.enabled(seqs.size() + 2)) { g_asm_dumps.push_back("X\n"); continue; }      // (+ 2: the entries of GAP::seq that are not counted)
         pbh::Graph<WL> low;
         pbh::Graph<WH> high;
         pbo::gap_assemble<WL, WH>(seqs, kl, kh, min_cov, low, high);
-        std::ostringstream o;
         o << std::hex << "L\n";
         dump_graph<WL>(o, low, kl);
         o << "H\n";
         dump_graph<WH>(o, high, kh);
+        if (have_flanks) {
+            if (!at_end) {
+                pbh::GapClosure c;
+                const bool closed = cl.closed(high, c);
+                closure_line(o, "C", closed, c, false);
+                if (!closed) { pbh::GapClosure pc; const bool part = cl.closed_partial(high, pc); closure_line(o, "P", part, pc, true); }
+            } else {
+                pbh::GapClosure c;
+                const bool ext = cl.extend_edge(high, c);
+                closure_line(o, "E", ext, c, false);
+            }
+        }
         g_asm_dumps.push_back(o.str());
     }
 }
 } // namespace
 extern "C" int pbo_gap_assemble_run(unsigned k_low, unsigned k_high, long min_cov, unsigned long long n_gaps, const unsigned long long *seq_first,
-                                    const unsigned long long *seq_off, const unsigned char *codes)
+                                    const unsigned long long *seq_off, const unsigned char *codes, const unsigned char *flanks)
 {
     const int wl = pbh::words_for_k(k_low), wh = pbh::words_for_k(k_high);
     try {
-        if (wl == 1 && wh == 1) asm_run<1, 1>(k_low, k_high, min_cov, n_gaps, seq_first, seq_off, codes);
-        else if (wl == 1 && wh == 2) asm_run<1, 2>(k_low, k_high, min_cov, n_gaps, seq_first, seq_off, codes);
-        else if (wl == 1 && wh == 3) asm_run<1, 3>(k_low, k_high, min_cov, n_gaps, seq_first, seq_off, codes);
-        else if (wl == 1 && wh == 4) asm_run<1, 4>(k_low, k_high, min_cov, n_gaps, seq_first, seq_off, codes);
-        else if (wl == 2 && wh == 3) asm_run<2, 3>(k_low, k_high, min_cov, n_gaps, seq_first, seq_off, codes);
+        if (wl == 1 && wh == 1) asm_run<1, 1>(k_low, k_high, min_cov, n_gaps, seq_first, seq_off, codes, flanks);
+        else if (wl == 1 && wh == 2) asm_run<1, 2>(k_low, k_high, min_cov, n_gaps, seq_first, seq_off, codes, flanks);
+        else if (wl == 1 && wh == 3) asm_run<1, 3>(k_low, k_high, min_cov, n_gaps, seq_first, seq_off, codes, flanks);
+        else if (wl == 1 && wh == 4) asm_run<1, 4>(k_low, k_high, min_cov, n_gaps, seq_first, seq_off, codes, flanks);
+        else if (wl == 2 && wh == 3) asm_run<2, 3>(k_low, k_high, min_cov, n_gaps, seq_first, seq_off, codes, flanks);
         else return -2;
     } catch (...) { return -1; }
     return 0;

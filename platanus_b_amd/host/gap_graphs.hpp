@@ -152,3 +152,154 @@ void gap_assemble_batch(pb_ctx *ctx, unsigned k_low, unsigned k_high, long min_c
 }
 
 } // namespace pbh
+
+// ---- what a gap's final graph says about the gap: GapCloseDBG<M, N>::closedGap / closedGapPartial / extendEdgeEntity ------------------------
+// (gapCloseDBG.h:479-741).  The flanks are GAP::headSeq (the bases in front of the gap, left to right) and GAP::tailSeq (behind it), codes
+// 0..3 / 4; a straight node's base p counts from its 3' end (graph.h:67-71), so its left-to-right base j is get(contig_length - 1 - j).
+namespace pbh {
+
+struct GapFlanks {
+    std::vector<char> head, tail;      // GAP::headSeq, GAP::tailSeq
+    int start = 0, end = 0;            // GAP::start, GAP::end (closedGapPartial's remaining length; extendEdge's side)
+};
+struct GapClosure {                    // GapCloseDBG::seq, seqLength, remainedGap
+    std::vector<char> seq;
+    int seq_length = 0, remained_gap = 0;
+};
+
+struct GapCloser {
+    unsigned max_k = 0, min_overlap = 32;      // maxKmer; -vd (gapClose.cpp:57)
+    double max_miss_rate = 0.01;               // -ed (gapClose.cpp:60)
+    const GapFlanks *gap = nullptr;
+
+    // gapCloseDBG.h:599-635: the longest suffix-of-head / prefix-of-node overlap within the error rate, and its error rate
+    std::pair<long, double> mismatch_left(const Straight &st) const
+    {
+        long overlap = 0;
+        double miss_rate = 1.0;
+        const long contig_length = (long)(st.length + max_k - 1);
+        const unsigned long long head_size = gap->head.size();
+        for (long length = contig_length; length >= (long)min_overlap; --length) {
+            double tol = length * max_miss_rate + 0.5;
+            unsigned long long miss = 0;
+            long i = 0;
+            for (; i < (long)min_overlap; ++i)
+                if (gap->head[head_size - 1 - i] != (char)st.get((u64)(contig_length - length + i))) { ++miss; if (miss > tol) break; }
+            if (i < (long)min_overlap) continue;
+            const long max_overlap = (long)std::min<unsigned long long>((unsigned long long)length, head_size);
+            tol = max_overlap * max_miss_rate + 0.5;
+            for (; i < max_overlap; ++i)
+                if (gap->head[head_size - 1 - i] != (char)st.get((u64)(contig_length - length + i))) { ++miss; if (miss > tol) break; }
+            if (miss <= tol && static_cast<double>(miss) / i < miss_rate) { miss_rate = static_cast<double>(miss) / i; overlap = length; }
+        }
+        return {overlap, miss_rate};
+    }
+    // gapCloseDBG.h:640-676
+    std::pair<long, double> mismatch_right(const Straight &st) const
+    {
+        long overlap = 0;
+        double miss_rate = 1.0;
+        const long contig_length = (long)(st.length + max_k - 1);
+        for (long length = contig_length; length >= (long)min_overlap; --length) {
+            double tol = length * max_miss_rate + 0.5;
+            unsigned long long miss = 0;
+            long i = 0;
+            for (; i < (long)min_overlap; ++i)
+                if (gap->tail[i] != (char)st.get((u64)(length - 1 - i))) { ++miss; if (miss > tol) break; }
+            if (i < (long)min_overlap) continue;
+            const long max_overlap = (long)std::min<unsigned long long>((unsigned long long)length, (unsigned long long)gap->tail.size());
+            tol = max_overlap * max_miss_rate + 0.5;
+            for (; i < max_overlap; ++i)
+                if (gap->tail[i] != (char)st.get((u64)(length - 1 - i))) { ++miss; if (miss > tol) break; }
+            if (miss <= tol && static_cast<double>(miss) / i < miss_rate) { miss_rate = static_cast<double>(miss) / i; overlap = length; }
+        }
+        return {overlap, miss_rate};
+    }
+    bool enabled(size_t n_seqs) const { return gap->head.size() >= min_overlap && gap->tail.size() >= min_overlap && n_seqs >= 2; }     // gapCloseDBG.h:405-408
+
+    // gapCloseDBG.h:479-532: exactly one live node overlaps both flanks
+    template <int W> bool closed(Graph<W> &g, GapClosure &r) const
+    {
+        long max_left = 0, max_right = 0;
+        double min_rate = 1.0;
+        const Straight *best = nullptr;
+        for (auto &e : g.left) {
+            const Straight &st = e.second;
+            if (st.coverage == 65535) continue;
+            const auto left = mismatch_left(st);
+            if (left.first == 0) continue;
+            const auto right = mismatch_right(st);
+            if (right.first == 0) continue;
+            if (best != nullptr) return false;
+            const double rate = (right.second * right.first + left.second * left.first) / (right.first + left.first);
+            if (rate < min_rate) { max_left = left.first; max_right = right.first; min_rate = rate; best = &st; }
+        }
+        if (max_left == 0) return false;
+        const long contig_length = (long)(best->length + max_k - 1);
+        r.seq_length = (int)(contig_length - max_left - max_right);
+        if (r.seq_length > 0) {
+            for (int i = 0; i < r.seq_length; ++i) r.seq.emplace_back((char)best->get((u64)(contig_length - 1 - max_left - i)));
+        } else {
+            const unsigned long long t = (unsigned long long)(-r.seq_length);
+            if (t > gap->head.size() || t > gap->tail.size()) return false;
+            for (int i = 0; i < -r.seq_length; ++i)
+                if (gap->head[gap->head.size() - 1 - i] != gap->tail[-r.seq_length - 1 - i]) return false;
+            --r.seq_length;
+        }
+        return true;
+    }
+    // gapCloseDBG.h:535-596: the best node on either side, unknown bases between them
+    template <int W> bool closed_partial(Graph<W> &g, GapClosure &r) const
+    {
+        const int MIN_GAP_LENGTH = 10;
+        long max_left = 0, max_right = 0;
+        double min_left_rate = 1.0, min_right_rate = 1.0;
+        const Straight *ls = nullptr, *rs = nullptr;
+        for (auto &e : g.left) {
+            const Straight &st = e.second;
+            if (st.coverage == 65535) continue;
+            const auto left = mismatch_left(st);
+            if (left.first > 0 && (left.second < min_left_rate || (left.second < min_left_rate && left.first > max_left))) {
+                max_left = left.first; min_left_rate = left.second; ls = &st;
+                continue;
+            }
+            const auto right = mismatch_right(st);
+            if (right.first > 0 && (right.second < min_right_rate || (right.second < min_right_rate && right.first > max_right))) {
+                max_right = right.first; min_right_rate = right.second; rs = &st;
+            }
+        }
+        if (max_left == 0 && max_right == 0) return false;
+        const int lcl = ls != nullptr ? (int)(ls->length + max_k - 1) : 0, rcl = rs != nullptr ? (int)(rs->length + max_k - 1) : 0;
+        r.seq_length = (int)((lcl - max_left) + (rcl - max_right));
+        int gap_length = MIN_GAP_LENGTH;
+        if ((gap->end - gap->start) - r.seq_length > MIN_GAP_LENGTH) gap_length = (gap->end - gap->start) - r.seq_length;
+        r.seq_length += gap_length;
+        r.remained_gap = gap_length;
+        for (int i = 0; i < lcl - max_left; ++i) r.seq.emplace_back((char)ls->get((u64)(lcl - 1 - max_left - i)));
+        for (int i = 0; i < gap_length; ++i) r.seq.emplace_back((char)4);
+        for (int i = 0; i < rcl - max_right; ++i) r.seq.emplace_back((char)rs->get((u64)i));
+        return true;
+    }
+    // gapCloseDBG.h:687-741: a gap at a scaffold's end: the node that continues the one flank there is
+    template <int W> bool extend_edge(Graph<W> &g, GapClosure &r) const
+    {
+        double min_rate = 1.0;
+        long min_rate_overlap = 0;
+        const Straight *best = nullptr;
+        for (auto &e : g.left) {
+            const Straight &st = e.second;
+            if (st.coverage == 65535) continue;
+            const auto edge = gap->start != 0 ? mismatch_left(st) : mismatch_right(st);
+            if (edge.second < min_rate) { min_rate_overlap = edge.first; min_rate = edge.second; best = &st; }
+        }
+        if (min_rate_overlap == 0) return false;
+        const long contig_length = (long)(best->length + max_k - 1);
+        r.seq_length = (int)(contig_length - min_rate_overlap);
+        if (r.seq_length <= 0) return false;
+        if (gap->start != 0) for (long i = 0; i < r.seq_length; ++i) r.seq.emplace_back((char)best->get((u64)(contig_length - 1 - min_rate_overlap - i)));
+        else for (long i = 0; i < r.seq_length; ++i) r.seq.emplace_back((char)best->get((u64)(contig_length - 1 - i)));
+        return true;
+    }
+};
+
+} // namespace pbh

@@ -59,3 +59,53 @@ ASSEMBLE_CASES = {
     "asm_32_100": (32, 100, 2, "k100_c2"),
     "asm_40_90": (40, 90, 3, "k75_c2"),
 }
+
+
+# gaps WITH flanks (GAP::headSeq / tailSeq / start / end) for the closing decisions (gapCloseDBG.h:479-741): name -> (k_low, k_high, seed, gaps)
+CLOSE_CASES = {
+    "close_20_80": (20, 80, 301, 60),
+    "close_25_60": (25, 60, 302, 40),
+    "close_40_90": (40, 90, 303, 30),
+}
+
+
+def make_gaps_with_flanks(name):
+    """A region = [left contig end][gap][right contig start]; reads from the whole region (20-40x, 150 bases, 0.5 % errors); the flanks are the
+    last / first 40-120 bases of the contigs, sometimes with an error, sometimes too short (< 32: not enabled), sometimes the gap lies at a
+    scaffold's end (start = 0 or the right end: extendEdge).  Some gaps get too few reads to be closed (partial closing or nothing)."""
+    import struct
+    kl, kh, seed, n_gaps = CLOSE_CASES[name]
+    rng = np.random.default_rng(seed)
+    seqs, first, flanks = [], [0], b""
+    for g in range(n_gaps):
+        hl, tl = int(rng.integers(40, 120)), int(rng.integers(40, 120))
+        if rng.random() < 0.1:
+            hl = int(rng.integers(5, 31))
+        G = int(rng.integers(30, 900))
+        region = rng.integers(0, 4, 200 + hl + G + tl + 200).astype(np.uint8)
+        lo, hi = 200, 200 + hl + G + tl
+        cov = float(rng.choice([3, 12, 25, 40]))
+        n_reads = max(2, int((hi - lo + 300) * cov / 150))
+        holes = rng.random() < 0.25                                   # a stretch of the gap that no read covers
+        for _ in range(n_reads):
+            L = 150
+            s = int(rng.integers(lo - 150, hi + 1))
+            s = max(0, min(s, len(region) - L))
+            if holes and s < lo + hl + G // 2 < s + L:
+                continue
+            r = region[s:s + L].copy()
+            e = rng.random(L) < 0.005
+            r[e] = (r[e] + 1 + rng.integers(0, 3, int(e.sum()))) & 3
+            seqs.append(r)
+        first.append(len(seqs))
+        head = region[lo:lo + hl].copy()
+        tail = region[lo + hl + G:hi].copy()
+        if rng.random() < 0.2:
+            head[int(rng.integers(0, len(head)))] ^= 1                # a mismatch inside a flank
+        u = rng.random()
+        at_end = u < 0.25
+        start = 0 if u < 0.12 else 5000 + g
+        end = start + G + int(rng.integers(-20, 20))
+        flanks += struct.pack("<iiBII", start, end, 1 if at_end else 0, len(head), len(tail)) + head.tobytes() + tail.tobytes()
+    off = np.concatenate([[0], np.cumsum([len(s) for s in seqs])]).astype(np.uint64)
+    return kl, kh, np.array(first, dtype=np.uint64), off, np.concatenate(seqs), flanks

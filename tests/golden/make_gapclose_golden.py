@@ -27,3 +27,11 @@ for name, (kl, kh, mc, case) in gapclose_cases.ASSEMBLE_CASES.items():
         for g, d in enumerate(dumps):
             f.write(f"G {g}\n{d}")
     print(name, "gaps", len(dumps), "lines", sum(d.count("\n") for d in dumps))
+
+for name in gapclose_cases.CLOSE_CASES:
+    kl, kh, first, off, codes, flanks = gapclose_cases.make_gaps_with_flanks(name)
+    dumps = pyoracle.gap_assemble_reference(kl, kh, 2, first, off, codes, flanks)      # ... and the reference's closing decisions (gapClose.cpp:716-760 without OLC)
+    with open(os.path.join(out_dir, name + ".txt"), "w") as f:
+        for g, d in enumerate(dumps):
+            f.write(f"G {g}\n{d}")
+    print(name, "gaps", len(dumps), "lines", sum(d.count("\n") for d in dumps))

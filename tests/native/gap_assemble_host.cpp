@@ -3,6 +3,7 @@
 // harness's format -- so that its output can be compared with dumps of the reference's own GapCloseDBG<M, N>::gapAssemble tables.
 // usage: gap_assemble_host INPUT.bin K_HIGH > dump.txt      (needs a GPU)
 //        gap_assemble_host INPUT.bin K_HIGH time            no dump: wall time of gap_assemble_batch and the nodes left, one line
+//        gap_assemble_host INPUT.bin K_HIGH FLANKS.bin      ... and the closing decisions (pbh::GapCloser: closedGap / closedGapPartial / extendEdge), as the harness prints them
 #include "../../platanus_b_amd/host/gap_graphs.hpp"
 #include <chrono>
 #include <cstdio>
@@ -30,6 +31,14 @@ template <int W> static void dump(pbh::Graph<W> &gr, unsigned k)
     }
 }
 static bool g_time_only = false;
+static FILE *g_flanks = nullptr;
+static void closure_line(const char *tag, bool ok, const pbh::GapClosure &c, bool with_remained)
+{
+    printf("%s %d %d", tag, ok ? 1 : 0, ok ? c.seq_length : 0);
+    if (with_remained) printf(" %d", ok ? c.remained_gap : 0);
+    if (ok) for (char b : c.seq) printf(" %d", (int)b);
+    printf("\n");
+}
 template <int WL, int WH> static void run(pb_ctx *ctx, unsigned kl, unsigned kh, long mc, const pbh::GapBatch &b)
 {
     std::vector<pbh::Graph<WL>> low;
@@ -46,10 +55,35 @@ template <int WL, int WH> static void run(pb_ctx *ctx, unsigned kl, unsigned kh,
         return;
     }
     for (size_t g = 0; g < low.size(); ++g) {
-        printf("G %zu\nL\n", g);
+        pbh::GapFlanks fl;
+        bool at_end = false;
+        if (g_flanks) {
+            int32_t se[2]; uint8_t e; uint32_t hl, tl;
+            if (fread(se, 4, 2, g_flanks) != 2 || fread(&e, 1, 1, g_flanks) != 1 || fread(&hl, 4, 1, g_flanks) != 1 || fread(&tl, 4, 1, g_flanks) != 1) exit(7);
+            fl.start = se[0]; fl.end = se[1]; at_end = e != 0;
+            fl.head.resize(hl); fl.tail.resize(tl);
+            if ((hl && fread(fl.head.data(), 1, hl, g_flanks) != hl) || (tl && fread(fl.tail.data(), 1, tl, g_flanks) != tl)) exit(7);
+        }
+        pbh::GapCloser cl;
+        cl.max_k = kh; cl.gap = &fl;
+        printf("G %zu\n", g);
+        // (gapClose.cpp:716-717: a gap that is not enabled is not assembled at all; here its graphs exist -- the batch built them -- and are not shown)
+        if (g_flanks && !at_end && !cl.enabled((size_t)(b.seq_first[g + 1] - b.seq_first[g]) + 2)) { printf("X\n"); continue; }
+        printf("L\n");
         dump<WL>(low[g], kl);
         printf("H\n");
         dump<WH>(high[g], kh);
+        if (!g_flanks) continue;
+        if (!at_end) {
+            pbh::GapClosure c;
+            const bool closed = cl.closed(high[g], c);
+            closure_line("C", closed, c, false);
+            if (!closed) { pbh::GapClosure pc; const bool part = cl.closed_partial(high[g], pc); closure_line("P", part, pc, true); }
+        } else {
+            pbh::GapClosure c;
+            const bool ext = cl.extend_edge(high[g], c);
+            closure_line("E", ext, c, false);
+        }
     }
 }
 
@@ -71,6 +105,7 @@ int main(int argc, char **argv)
     b.seq_first = seq_first; b.seq_off = seq_off; b.codes = codes;
     const unsigned kh = (unsigned)atoi(argv[2]);
     g_time_only = argc >= 4 && !strcmp(argv[3], "time");
+    if (argc >= 4 && !g_time_only && !(g_flanks = fopen(argv[3], "rb"))) return 2;
     pb_ctx *ctx = nullptr;
     if (pb_create(0, &ctx) != PB_OK) { fprintf(stderr, "%s\n", pb_last_error(nullptr)); return 4; }
     try {

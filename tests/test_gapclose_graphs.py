@@ -197,3 +197,45 @@ def test_device_gap_assembly_against_the_reference_tables(name, gap_assemble_hos
     assert len(got) == len(gold)
     for g, (a, b) in enumerate(zip(got, gold)):
         assert a == b, f"{name}: graphs of gap {g} differ from the reference's"
+
+
+@pytest.mark.parametrize("name", sorted(gapclose_cases.CLOSE_CASES))
+def test_oracle_gap_closing_decisions_against_the_reference(name, oracle_built):
+    """What the reference decides about a gap from its final graph and the gap's flanks -- closedGap, closedGapPartial, extendEdgeEntity
+    (gapCloseDBG.h:479-741; the order of gapClose.cpp:716-760 without the OLC fallback; -vd 32, -ed 0.01) -- restated in
+    platanus_b_amd/host/gap_graphs.hpp (GapCloser): closed / partly closed / extended / nothing, the closing sequence base for base."""
+    from oracle import pyoracle
+    kl, kh, first, off, codes, flanks = gapclose_cases.make_gaps_with_flanks(name)
+    dumps = pyoracle.gap_assemble(kl, kh, 2, first, off, codes, flanks)
+    gold = _golden(name)
+    assert len(dumps) == len(gold)
+    for g, (a, b) in enumerate(zip(dumps, gold)):
+        assert a == b, f"{name}: gap {g} differs from the reference's"
+    text = "".join(gold)
+    for tag in ("\nC 1", "\nC 0", "\nP 1", "\nE 1", "X\n"):
+        assert tag in text, f"{name}: no {tag!r} case"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(gapclose_cases.CLOSE_CASES))
+def test_device_gap_closing_decisions_against_the_reference(name, gap_assemble_host, tmp_path):
+    """The same through the product: the graphs of all gaps by gap_assemble_batch (device + host cleaning), the decisions by GapCloser."""
+    import struct
+    import subprocess
+    from oracle import pyoracle
+    kl, kh, first, off, codes, flanks = gapclose_cases.make_gaps_with_flanks(name)
+    inp, fl = tmp_path / "gaps.bin", tmp_path / "flanks.bin"
+    with open(inp, "wb") as f:
+        f.write(struct.pack("<IqQ", kl, 2, len(first) - 1))
+        f.write(first.tobytes())
+        f.write(struct.pack("<Q", len(off) - 1))
+        f.write(off.tobytes())
+        f.write(codes[:int(off[-1])].tobytes())
+    fl.write_bytes(flanks)
+    p = subprocess.run([gap_assemble_host, str(inp), str(kh), str(fl)], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    got = pyoracle.split_gap_dump(p.stdout)
+    gold = _golden(name)
+    assert len(got) == len(gold)
+    for g, (a, b) in enumerate(zip(got, gold)):
+        assert a == b, f"{name}: gap {g} differs from the reference's"
